@@ -1,0 +1,176 @@
+"""Static description of the ResUNet30 separator: block table, parameter names/shapes, FiLM sites.
+
+This is the single source of truth the host mirror (`lass_amd.resunet`), the C-ABI weight upload, the
+synthetic-weight generator and the tests all read.  Names are the reference's `state_dict` keys so that
+reference checkpoints load unchanged.
+
+Reference: /root/reference/models/resunet.py
+  - STFT geometry            :271-276  (n_fft = win = 1024, hop 160, centre, reflect, hann)
+  - block table              :304-427
+  - ConvBlockRes params      :84-145
+  - DecoderBlockRes1B params :201-238  (bn2 exists, is in the state_dict, and is never used :230,254)
+  - FiLM naming ('a->b->beta1', pre-order) :21-57, get_film_meta :598-618
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Tuple
+
+N_FFT = 1024
+HOP = 160
+N_BINS = N_FFT // 2 + 1          # 513
+F_CROP = N_BINS - 1              # 512   (resunet.py:552)
+T_DOWN = 32                      # resunet.py:282
+K_MASK = 3                       # resunet.py:280
+BN_EPS = 1e-5                    # nn.BatchNorm2d default, resunet.py:98-99
+LEAKY = 0.01                     # resunet.py:159-160,255
+PRE_CH = 32                      # resunet.py:306-313
+
+
+@dataclass(frozen=True)
+class EncSpec:
+    name: str
+    cin: int
+    cout: int
+    down: Tuple[int, int]
+
+
+@dataclass(frozen=True)
+class DecSpec:
+    name: str
+    cin: int
+    cout: int
+    up: Tuple[int, int]
+
+
+ENCODERS: Tuple[EncSpec, ...] = (
+    EncSpec("encoder_block1", 32, 32, (2, 2)),
+    EncSpec("encoder_block2", 32, 64, (2, 2)),
+    EncSpec("encoder_block3", 64, 128, (2, 2)),
+    EncSpec("encoder_block4", 128, 256, (2, 2)),
+    EncSpec("encoder_block5", 256, 384, (2, 2)),
+    EncSpec("encoder_block6", 384, 384, (1, 2)),
+    EncSpec("conv_block7a", 384, 384, (1, 1)),
+)
+
+DECODERS: Tuple[DecSpec, ...] = (
+    DecSpec("decoder_block1", 384, 384, (1, 2)),
+    DecSpec("decoder_block2", 384, 384, (2, 2)),
+    DecSpec("decoder_block3", 384, 256, (2, 2)),
+    DecSpec("decoder_block4", 256, 128, (2, 2)),
+    DecSpec("decoder_block5", 128, 64, (2, 2)),
+    DecSpec("decoder_block6", 64, 32, (2, 2)),
+)
+
+
+def frames_for(length: int) -> int:
+    """Centred STFT frame count (torchlibrosa STFT with center=True)."""
+    return 1 + length // HOP
+
+
+def padded_frames(t: int) -> int:
+    """resunet.py:543-548."""
+    return ((t + T_DOWN - 1) // T_DOWN) * T_DOWN
+
+
+def _bn(prefix: str, c: int) -> List[Tuple[str, Tuple[int, ...], str]]:
+    return [
+        (prefix + ".weight", (c,), "bn_weight"),
+        (prefix + ".bias", (c,), "bn_bias"),
+        (prefix + ".running_mean", (c,), "bn_mean"),
+        (prefix + ".running_var", (c,), "bn_var"),
+        (prefix + ".num_batches_tracked", (), "bn_nbt"),
+    ]
+
+
+def _conv_block_res(prefix: str, cin: int, cout: int):
+    out = []
+    out += _bn(prefix + ".bn1", cin)
+    out += _bn(prefix + ".bn2", cout)
+    out.append((prefix + ".conv1.weight", (cout, cin, 3, 3), "conv_w"))
+    out.append((prefix + ".conv2.weight", (cout, cout, 3, 3), "conv_w"))
+    if cin != cout:
+        out.append((prefix + ".shortcut.weight", (cout, cin, 1, 1), "conv_w"))
+        out.append((prefix + ".shortcut.bias", (cout,), "bias"))
+    return out
+
+
+def film_sites() -> List[Tuple[str, int, bool]]:
+    """(film module name, channels, used) in the reference's pre-order (resunet.py:598-618, :21-49).
+
+    `decoder_blockN->beta2` is created (DecoderBlockRes1B.bn2 exists) but its output is never read.
+    """
+    sites: List[Tuple[str, int, bool]] = []
+    for e in ENCODERS:
+        sites.append((f"{e.name}->conv_block1->beta1", e.cin, True))
+        sites.append((f"{e.name}->conv_block1->beta2", e.cout, True))
+    for d in DECODERS:
+        sites.append((f"{d.name}->beta1", d.cin, True))
+        sites.append((f"{d.name}->beta2", d.cin, False))
+        sites.append((f"{d.name}->conv_block2->beta1", 2 * d.cout, True))
+        sites.append((f"{d.name}->conv_block2->beta2", d.cout, True))
+    return sites
+
+
+def param_specs(input_channels: int = 1, output_channels: int = 1, condition_size: int = 512):
+    """Ordered [(state_dict key, shape, kind)] for `ResUNet30(input_channels, output_channels, condition_size)`.
+
+    Keys carry the `base.` / `film.` prefixes of resunet.py:625-637.  torchlibrosa's frozen conv buffers
+    (`base.stft.*`, `base.istft.*`) are deliberately absent: they are constants of the STFT geometry, not weights.
+    """
+    specs: List[Tuple[str, Tuple[int, ...], str]] = []
+    specs += _bn("base.bn0", N_BINS)
+    specs.append(("base.pre_conv.weight", (PRE_CH, input_channels, 1, 1), "conv_w"))
+    specs.append(("base.pre_conv.bias", (PRE_CH,), "bias"))
+    for e in ENCODERS:
+        specs += _conv_block_res(f"base.{e.name}.conv_block1", e.cin, e.cout)
+    for d in DECODERS:
+        specs.append((f"base.{d.name}.conv1.weight", (d.cin, d.cout, d.up[0], d.up[1]), "tconv_w"))
+        specs += _bn(f"base.{d.name}.bn1", d.cin)
+        specs += _conv_block_res(f"base.{d.name}.conv_block2", 2 * d.cout, d.cout)
+        specs += _bn(f"base.{d.name}.bn2", d.cin)
+    specs.append(("base.after_conv.weight", (output_channels * K_MASK, PRE_CH, 1, 1), "conv_w"))
+    specs.append(("base.after_conv.bias", (output_channels * K_MASK,), "bias"))
+    for name, c, _used in film_sites():
+        specs.append((f"film.{name}.weight", (c, condition_size), "linear_w"))
+        specs.append((f"film.{name}.bias", (c,), "linear_b"))
+    return specs
+
+
+def conv_layer_table(t_pad: int, f: int = F_CROP) -> List[Dict]:
+    """Every conv / transposed-conv the U-Net executes, with MAC counts per clip.
+
+    Used by bench.py for the algorithmic-FLOP numerator and by DESIGN.md.
+    """
+    rows: List[Dict] = []
+    h, w = t_pad, f
+    rows.append(dict(name="pre_conv", kind="1x1", cin=1, cout=PRE_CH, h=h, w=w, macs=h * w * PRE_CH))
+    skips = []
+    for e in ENCODERS:
+        rows.append(dict(name=e.name + ".conv1", kind="3x3", cin=e.cin, cout=e.cout, h=h, w=w,
+                         macs=h * w * 9 * e.cin * e.cout))
+        rows.append(dict(name=e.name + ".conv2", kind="3x3", cin=e.cout, cout=e.cout, h=h, w=w,
+                         macs=h * w * 9 * e.cout * e.cout))
+        if e.cin != e.cout:
+            rows.append(dict(name=e.name + ".shortcut", kind="1x1", cin=e.cin, cout=e.cout, h=h, w=w,
+                             macs=h * w * e.cin * e.cout))
+        skips.append((h, w))
+        h, w = h // e.down[0], w // e.down[1]
+    skips.pop()  # conv_block7a's un-pooled output is discarded (resunet.py:562)
+    for d in DECODERS:
+        rows.append(dict(name=d.name + ".up", kind="tconv", cin=d.cin, cout=d.cout, h=h, w=w,
+                         macs=h * w * d.cin * d.cout * d.up[0] * d.up[1]))
+        h, w = h * d.up[0], w * d.up[1]
+        assert (h, w) == skips.pop()
+        rows.append(dict(name=d.name + ".conv1", kind="3x3", cin=2 * d.cout, cout=d.cout, h=h, w=w,
+                         macs=h * w * 9 * 2 * d.cout * d.cout))
+        rows.append(dict(name=d.name + ".conv2", kind="3x3", cin=d.cout, cout=d.cout, h=h, w=w,
+                         macs=h * w * 9 * d.cout * d.cout))
+        rows.append(dict(name=d.name + ".shortcut", kind="1x1", cin=2 * d.cout, cout=d.cout, h=h, w=w,
+                         macs=h * w * 2 * d.cout * d.cout))
+    rows.append(dict(name="after_conv", kind="1x1", cin=PRE_CH, cout=K_MASK, h=h, w=w, macs=h * w * PRE_CH * K_MASK))
+    return rows
+
+
+def conv_macs_per_clip(length: int) -> int:
+    return sum(r["macs"] for r in conv_layer_table(padded_frames(frames_for(length))))
