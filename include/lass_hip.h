@@ -1,0 +1,138 @@
+/*
+ * lass_hip.h - C-ABI of liblass_hip.so: the MI355X (gfx950) text-conditioned separation hot path.
+ *
+ *     mixture (B,L) f32 + condition (B,512) f32  --STFT--> |X|,cos,sin --FiLM ResUNet30--> mask --iSTFT--> (B,L) f32
+ *
+ * The reference (reedrosenbluth/LASS) is pure Python and has no FFI of its own; this boundary replaces what its
+ * evaluator calls two levels down:  `pl_model.ss_model(input_dict)["waveform"]`  (dcase_evaluator.py:99-107), i.e.
+ * `ResUNet30.forward` (models/resunet.py:640-653) = `FiLM.forward` (:59-81) + `ResUNet30_Base.forward` (:522-595),
+ * plus the numpy metrics `calculate_sdr` / `calculate_sisdr` (utils.py:148-200).  Each entry point below cites the
+ * reference code it stands in for.  INTEGRATION.md shows the ctypes binding a maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes; no torch / C++ types.  All tensor pointers are DEVICE pointers unless said otherwise.
+ *   - every function returns 0 on success, <0 on error; `lass_last_error(ctx)` has the message.
+ *   - kernels are enqueued on the caller's `stream` (a hipStream_t passed as void*) and never synchronise.
+ *   - the caller owns inputs, outputs and the workspace; the context owns re-laid-out weights and constant tables.
+ *     `lass_separate` allocates nothing.
+ *   - one context per (process, device); not re-entrant per context.
+ *   - there is NO CPU fallback: without a gfx950 device `lass_create` fails.
+ */
+#ifndef LASS_HIP_H
+#define LASS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lass_ctx lass_ctx;
+
+/* error codes */
+#define LASS_OK 0
+#define LASS_ERR_ARG (-1)      /* bad argument / shape */
+#define LASS_ERR_HIP (-2)      /* a HIP runtime call failed */
+#define LASS_ERR_STATE (-3)    /* call order (e.g. separate before finalize, missing parameter) */
+#define LASS_ERR_WORKSPACE (-4)/* workspace too small */
+
+/* dtypes for lass_set_param */
+#define LASS_F32 0
+#define LASS_I64 1
+
+/* compute modes for lass_finalize */
+#define LASS_COMPUTE_F32 0     /* f32 storage, v_mfma_f32_32x32x2_f32 contractions (bit-exact f32 FMA chains) */
+
+/* Library / ABI version (major*10000 + minor*100 + patch). */
+int lass_version(void);
+
+/* Create a context on HIP device `device_id`.  Builds the FFT twiddle / Hann tables.
+ * Replaces: ResUNet30.__init__ (resunet.py:621-637) + torchlibrosa STFT/ISTFT construction (:284-302). */
+int lass_create(lass_ctx** out, int device_id);
+int lass_destroy(lass_ctx* ctx);
+
+/* Last error message of this context (or of the failed lass_create when ctx == NULL). Never NULL. */
+const char* lass_last_error(const lass_ctx* ctx);
+
+/* Upload one tensor of the reference's state_dict (key relative to ss_model, e.g.
+ * "base.encoder_block1.conv_block1.conv1.weight", "film.decoder_block3->conv_block2->beta1.bias").
+ * `data` may be a host or a device pointer (copied with hipMemcpyDefault); shape/dtype are checked against the
+ * architecture.  Unknown keys that a reference checkpoint legitimately carries (base.stft.*, base.istft.*,
+ * *.num_batches_tracked, decoder_block*.bn2.*, film.decoder_block*->beta2.*) are accepted and ignored (returns 1).
+ * Replaces: nn.Module.load_state_dict as used by utils.load_ss_model (utils.py:356-400). */
+int lass_set_param(lass_ctx* ctx, const char* name, const void* data, const int64_t* shape, int ndim, int dtype);
+
+/* Fold BatchNorm (eval mode, eps 1e-5) into per-channel scale/shift tables, concatenate the 32 live FiLM linears into
+ * one matrix, re-lay-out conv weights to [cin][tap][cout].  Fails if a required parameter is missing.
+ * Must be called again after any lass_set_param. */
+int lass_finalize(lass_ctx* ctx, int compute_mode);
+
+/* Bytes of workspace `lass_separate` needs for B clips of L samples. */
+int lass_workspace_bytes(const lass_ctx* ctx, int B, int L, size_t* bytes);
+
+/* The hot path.  mixture (B,L) f32, condition (B,512) f32 -> out (B,L) f32.
+ * Replaces: ResUNet30.forward(input_dict)["waveform"] (resunet.py:640-653) with mixture/out squeezed of their
+ * singleton channel axis. */
+int lass_separate(lass_ctx* ctx, const float* mixture, const float* condition, float* out, int B, int L,
+                  void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- stage entry points (used by the parity tests; same kernels lass_separate launches) --------------------- */
+
+/* Centred STFT (n_fft=win=1024, hop 160, reflect pad, periodic Hann) fused with magnitude/phase.
+ * wav (B,L) -> mag, cos, sin (B,T,513), T = 1 + L/160.  Any of mag/cos/sin/real/imag may be NULL.
+ * mag = sqrt(max(re^2+im^2, 1e-10)), cos = re/mag, sin = im/mag.
+ * Replaces: Base.wav_to_spectrogram_phase (base.py:83-113) + torchlibrosa STFT.forward. */
+int lass_stft_magphase(lass_ctx* ctx, const float* wav, int B, int L, float* mag, float* cos_out, float* sin_out,
+                       float* real_out, float* imag_out, void* stream);
+
+/* Inverse STFT: real, imag (B,T,513) -> wav (B,L).  frames_ws: scratch of B*T*1024 floats.
+ * Replaces: torchlibrosa ISTFT.forward as called at resunet.py:510. */
+int lass_istft(lass_ctx* ctx, const float* real, const float* imag, int B, int T, int L, float* wav,
+               float* frames_ws, void* stream);
+
+/* FiLM + BN folding for a batch of conditions: shift (B, n_shift) where n_shift = lass_film_width(ctx); column
+ * layout is given by lass_film_offset().  shift[b, off+c] = bn_beta[c] - mean[c]*s[c] + (W_site cond_b + b_site)[c].
+ * Replaces: FiLM.forward (resunet.py:59-81) for the 32 sites whose output is read. */
+int lass_film(lass_ctx* ctx, const float* condition, int B, float* shift, void* stream);
+int lass_film_width(const lass_ctx* ctx);
+/* Column offset of a site ("encoder_block1->conv_block1->beta1", "decoder_block2->beta1", ...) or -1. */
+int lass_film_offset(const lass_ctx* ctx, const char* site);
+/* Raw FiLM vectors (no BN folding): film (B, n_shift) = W cond + b.  For parity tests against the golden film vectors. */
+int lass_film_raw(lass_ctx* ctx, const float* condition, int B, float* film, void* stream);
+
+/* One residual block (resunet.py:147-165) by reference module prefix, e.g. "base.encoder_block2.conv_block1" or
+ * "base.decoder_block3.conv_block2".  x (B,Cin,H,W) NCHW f32 -> y (B,Cout,H,W).  shift is the lass_film() output for
+ * the same batch.  scratch: B*Cout*H*W floats. */
+int lass_convblock(lass_ctx* ctx, const char* prefix, const float* x, int B, int H, int W, const float* shift,
+                   float* y, float* scratch, void* stream);
+
+/* Transposed conv of a decoder block (resunet.py:254-255): x (B,Cin,h,w) -> y (B,Cout,h*sh,w*sw), with the
+ * bn1 + FiLM + leaky-ReLU prologue.  name: "base.decoder_blockN". */
+int lass_upconv(lass_ctx* ctx, const char* name, const float* x, int B, int h, int w, const float* shift, float* y,
+                void* stream);
+
+/* after_conv (1x1, 32->3, +bias) + complex-mask application (resunet.py:570-574, :469-495):
+ * x12 (B,32,Tpad,512), mag/cos/sin (B,T,513) -> out_real, out_imag (B,T,513); bin 512 is exactly 0. */
+int lass_mask_apply(lass_ctx* ctx, const float* x12, const float* mag, const float* cos_in, const float* sin_in,
+                    int B, int T, int Tpad, float* out_real, float* out_imag, void* stream);
+
+/* Per-clip statistics for SDR / SI-SDR (utils.py:148-200): stats (B,6) f64 =
+ * [sum ref^2, sum est^2, sum ref*est, sum (est-ref)^2, sum (a*ref)^2, sum (est-a*ref)^2],
+ * a = (eps32 + <ref,est>)/(<ref,ref> + eps32), eps32 = FLT_EPSILON.  dB math is the host's. */
+int lass_sdr_stats(lass_ctx* ctx, const float* ref, const float* est, int B, int L, double* stats, void* stream);
+
+/* ---- instrumentation ---------------------------------------------------------------------------------------- */
+
+/* When enabled, lass_separate brackets each kernel class with HIP events on `stream` (costs a few us per launch). */
+int lass_set_profiling(lass_ctx* ctx, int enabled);
+/* After a profiled lass_separate has completed (caller synchronised the stream): number of kernel classes, and for
+ * class i its name, accumulated milliseconds and launch count since the last lass_profile_reset. */
+int lass_profile_count(const lass_ctx* ctx);
+int lass_profile_get(lass_ctx* ctx, int i, const char** name, double* ms, int* launches);
+int lass_profile_reset(lass_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LASS_HIP_H */

@@ -1,0 +1,746 @@
+// api.hip - the C-ABI of include/lass_hip.h: context, weight ingestion/folding, workspace plan, forward orchestration.
+//
+// Forward order mirrors /root/reference/models/resunet.py:522-595 (ResUNet30_Base.forward) with FiLM (:59-81) hoisted to
+// one launch.  torch.cat of the decoder (:258) is virtual: encoder blocks write their skip output straight into the
+// second channel half of the decoder's concat buffer and the transposed conv writes the first half.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/lass_hip.h"
+#include "kernels.h"
+
+namespace {
+
+struct EncSpec { const char* name; int cin, cout, dh, dw; };
+struct DecSpec { const char* name; int cin, cout, uh, uw; };
+// resunet.py:315-418
+const EncSpec kEnc[7] = {{"encoder_block1", 32, 32, 2, 2},   {"encoder_block2", 32, 64, 2, 2},
+                         {"encoder_block3", 64, 128, 2, 2},  {"encoder_block4", 128, 256, 2, 2},
+                         {"encoder_block5", 256, 384, 2, 2}, {"encoder_block6", 384, 384, 1, 2},
+                         {"conv_block7a", 384, 384, 1, 1}};
+const DecSpec kDec[6] = {{"decoder_block1", 384, 384, 1, 2}, {"decoder_block2", 384, 384, 2, 2},
+                         {"decoder_block3", 384, 256, 2, 2}, {"decoder_block4", 256, 128, 2, 2},
+                         {"decoder_block5", 128, 64, 2, 2},  {"decoder_block6", 64, 32, 2, 2}};
+constexpr int kPreCh = 32;
+constexpr float kBnEps = 1e-5f;
+
+struct Raw {
+    float* d = nullptr;
+    std::vector<int64_t> shape;
+    size_t n = 0;
+};
+
+struct Site {
+    std::string film;  // "encoder_block1->conv_block1->beta1"
+    std::string bn;    // "base.encoder_block1.conv_block1.bn1"
+    int C = 0;
+    int off = 0;
+};
+
+struct ResBlock {  // one ConvBlockRes
+    std::string prefix;  // "base.encoder_block1.conv_block1"
+    int cin = 0, cout = 0;
+    int s1 = -1, s2 = -1;  // site indices
+    float *w1 = nullptr, *w2 = nullptr, *wsc = nullptr;  // re-laid-out
+    const float* bsc = nullptr;                         // raw shortcut bias
+};
+
+struct ProfEntry {
+    const char* name;
+    double ms = 0;
+    int launches = 0;
+};
+
+thread_local std::string g_create_err;
+
+}  // namespace
+
+struct lass_ctx {
+    int device = 0;
+    std::string err;
+    std::map<std::string, Raw> raw;
+    bool finalized = false;
+    float2* tw = nullptr;
+    float* win = nullptr;
+    std::vector<Site> sites;
+    std::map<std::string, int> site_idx;
+    int n_shift = 0;
+    float *film_W = nullptr, *film_b = nullptr, *bn_scale = nullptr, *bn_base = nullptr;
+    float *bn0_s = nullptr, *bn0_h = nullptr;
+    std::vector<ResBlock> enc, dec;  // 7 + 6
+    int dec_site[6] = {0};           // decoder_blockN->beta1
+    std::vector<void*> owned;        // derived device buffers to free
+    // profiling
+    bool profiling = false;
+    std::vector<ProfEntry> prof;
+    std::vector<hipEvent_t> ev_pool;
+    struct Pending { int cls; hipEvent_t a, b; };
+    std::vector<Pending> pending;
+    size_t ev_used = 0;
+};
+
+namespace {
+
+#define HIP_TRY(ctx, expr)                                                                                     \
+    do {                                                                                                       \
+        hipError_t _e = (expr);                                                                                \
+        if (_e != hipSuccess) {                                                                                \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(_e);                                     \
+            return LASS_ERR_HIP;                                                                               \
+        }                                                                                                      \
+    } while (0)
+
+int fail(lass_ctx* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+bool starts_with(const std::string& s, const char* p) { return s.rfind(p, 0) == 0; }
+bool ends_with(const std::string& s, const char* p) {
+    const size_t n = strlen(p);
+    return s.size() >= n && s.compare(s.size() - n, n, p) == 0;
+}
+
+std::string film_to_bn(const std::string& film) {  // 'a->b->beta1' -> 'base.a.b.bn1'
+    std::string s = "base.";
+    for (size_t i = 0; i < film.size(); ++i) {
+        if (film[i] == '-' && i + 1 < film.size() && film[i + 1] == '>') {
+            s += '.';
+            ++i;
+        } else {
+            s += film[i];
+        }
+    }
+    const size_t p = s.rfind("beta");
+    s.replace(p, 4, "bn");
+    return s;
+}
+
+int add_site(lass_ctx* c, const std::string& film, int C) {
+    Site s;
+    s.film = film;
+    s.bn = film_to_bn(film);
+    s.C = C;
+    s.off = c->n_shift;
+    c->n_shift += C;
+    c->site_idx[film] = (int)c->sites.size();
+    c->sites.push_back(s);
+    return (int)c->sites.size() - 1;
+}
+
+void build_arch(lass_ctx* c) {
+    c->sites.clear();
+    c->site_idx.clear();
+    c->n_shift = 0;
+    c->enc.clear();
+    c->dec.clear();
+    for (const auto& e : kEnc) {
+        ResBlock rb;
+        rb.prefix = std::string("base.") + e.name + ".conv_block1";
+        rb.cin = e.cin;
+        rb.cout = e.cout;
+        rb.s1 = add_site(c, std::string(e.name) + "->conv_block1->beta1", e.cin);
+        rb.s2 = add_site(c, std::string(e.name) + "->conv_block1->beta2", e.cout);
+        c->enc.push_back(rb);
+    }
+    for (int i = 0; i < 6; ++i) {
+        const auto& d = kDec[i];
+        c->dec_site[i] = add_site(c, std::string(d.name) + "->beta1", d.cin);
+        ResBlock rb;
+        rb.prefix = std::string("base.") + d.name + ".conv_block2";
+        rb.cin = 2 * d.cout;
+        rb.cout = d.cout;
+        rb.s1 = add_site(c, std::string(d.name) + "->conv_block2->beta1", 2 * d.cout);
+        rb.s2 = add_site(c, std::string(d.name) + "->conv_block2->beta2", d.cout);
+        c->dec.push_back(rb);
+    }
+}
+
+// Expected shape of a required parameter, or empty if the name is not one.
+std::vector<int64_t> expected_shape(const lass_ctx* c, const std::string& name) {
+    auto bn_field = [](const std::string& n) {
+        return ends_with(n, ".weight") || ends_with(n, ".bias") || ends_with(n, ".running_mean") ||
+               ends_with(n, ".running_var");
+    };
+    if (starts_with(name, "base.bn0.") && bn_field(name)) return {LASS_NBINS};
+    if (name == "base.pre_conv.weight") return {kPreCh, 1, 1, 1};
+    if (name == "base.pre_conv.bias") return {kPreCh};
+    if (name == "base.after_conv.weight") return {3, kPreCh, 1, 1};
+    if (name == "base.after_conv.bias") return {3};
+    auto res_block = [&](const ResBlock& rb) -> std::vector<int64_t> {
+        const std::string& p = rb.prefix;
+        if (!starts_with(name, (p + ".").c_str())) return {};
+        const std::string f = name.substr(p.size() + 1);
+        if (starts_with(f, "bn1.") && bn_field(f)) return {rb.cin};
+        if (starts_with(f, "bn2.") && bn_field(f)) return {rb.cout};
+        if (f == "conv1.weight") return {rb.cout, rb.cin, 3, 3};
+        if (f == "conv2.weight") return {rb.cout, rb.cout, 3, 3};
+        if (rb.cin != rb.cout && f == "shortcut.weight") return {rb.cout, rb.cin, 1, 1};
+        if (rb.cin != rb.cout && f == "shortcut.bias") return {rb.cout};
+        return {};
+    };
+    for (const auto& rb : c->enc) {
+        auto s = res_block(rb);
+        if (!s.empty()) return s;
+    }
+    for (int i = 0; i < 6; ++i) {
+        auto s = res_block(c->dec[i]);
+        if (!s.empty()) return s;
+        const std::string p = std::string("base.") + kDec[i].name;
+        if (name == p + ".conv1.weight") return {kDec[i].cin, kDec[i].cout, kDec[i].uh, kDec[i].uw};
+        if (starts_with(name, (p + ".bn1.").c_str()) && bn_field(name)) return {kDec[i].cin};
+    }
+    if (starts_with(name, "film.")) {
+        for (const auto& s : c->sites) {
+            if (name == "film." + s.film + ".weight") return {s.C, LASS_COND};
+            if (name == "film." + s.film + ".bias") return {s.C};
+        }
+    }
+    return {};
+}
+
+bool ignorable(const std::string& name) {
+    if (starts_with(name, "base.stft.") || starts_with(name, "base.istft.")) return true;
+    if (ends_with(name, "num_batches_tracked")) return true;
+    for (const auto& d : kDec) {
+        if (starts_with(name, (std::string("base.") + d.name + ".bn2.").c_str())) return true;      // resunet.py:230
+        if (starts_with(name, (std::string("film.") + d.name + "->beta2.").c_str())) return true;  // never read
+    }
+    return false;
+}
+
+const float* rawp(const lass_ctx* c, const std::string& name) {
+    auto it = c->raw.find(name);
+    return it == c->raw.end() ? nullptr : it->second.d;
+}
+
+template <typename T>
+int dev_alloc(lass_ctx* c, T** p, size_t count) {
+    void* v = nullptr;
+    HIP_TRY(c, hipMalloc(&v, count * sizeof(T)));
+    c->owned.push_back(v);
+    *p = (T*)v;
+    return 0;
+}
+
+void free_owned(lass_ctx* c) {
+    for (void* p : c->owned) (void)hipFree(p);
+    c->owned.clear();
+}
+
+// ---- profiling ----------------------------------------------------------------------------------------------------
+enum ProfClass { P_STFT = 0, P_FILM, P_PRECONV, P_CONV3X3, P_TCONV, P_POOL, P_MASK, P_ISTFT, P_COUNT };
+const char* kProfNames[P_COUNT] = {"stft_magphase", "film", "pre_conv", "conv3x3_mfma", "tconv_mfma",
+                                   "avg_pool",      "mask_apply", "istft"};
+
+struct ProfScope {
+    lass_ctx* c;
+    hipStream_t s;
+    int cls;
+    hipEvent_t b = nullptr;
+    bool on = false;
+    ProfScope(lass_ctx* ctx, hipStream_t st, int k) : c(ctx), s(st), cls(k) {
+        if (!c->profiling) return;
+        if (c->ev_used + 2 > c->ev_pool.size()) {
+            for (int i = 0; i < 64; ++i) {
+                hipEvent_t e;
+                if (hipEventCreate(&e) != hipSuccess) return;
+                c->ev_pool.push_back(e);
+            }
+        }
+        hipEvent_t a = c->ev_pool[c->ev_used++];
+        b = c->ev_pool[c->ev_used++];
+        (void)hipEventRecord(a, s);
+        c->pending.push_back({cls, a, b});
+        on = true;
+    }
+    ~ProfScope() {
+        if (on) (void)hipEventRecord(b, s);
+    }
+};
+
+void prof_collect(lass_ctx* c) {
+    for (auto& p : c->pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            c->prof[p.cls].ms += ms;
+            c->prof[p.cls].launches += 1;
+        }
+    }
+    c->pending.clear();
+    c->ev_used = 0;
+}
+
+// ---- one residual block ---------------------------------------------------------------------------------------------
+// x: (B,cin,H,W) batch stride x_bs; out: batch stride out_bs (may be a channel slice of a concat buffer).
+int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int B, int H, int W, const float* shift,
+                 float* a2, float* out, long out_bs, hipStream_t st) {
+    const Site& s1 = c->sites[rb.s1];
+    const Site& s2 = c->sites[rb.s2];
+    const long HW = (long)H * W;
+    ConvArgs p;
+    p.in = x; p.in_bs = x_bs; p.Cin = rb.cin; p.w = rb.w1; p.Nw = rb.cout; p.N = rb.cout;
+    p.pro_scale = c->bn_scale + s1.off; p.pro_shift = shift + s1.off; p.pro_shift_bs = c->n_shift;
+    p.epi_scale = c->bn_scale + s2.off; p.epi_shift = shift + s2.off; p.epi_shift_bs = c->n_shift;
+    p.out = a2; p.out_bs = rb.cout * HW; p.B = B; p.H = H; p.W = W;
+    {
+        ProfScope ps(c, st, P_CONV3X3);
+        HIP_TRY(c, lass_launch_conv(CONV1_ACT, p, st));
+    }
+    ConvArgs q;
+    q.in = a2; q.in_bs = rb.cout * HW; q.Cin = rb.cout; q.w = rb.w2; q.Nw = rb.cout; q.N = rb.cout;
+    q.out = out; q.out_bs = out_bs; q.B = B; q.H = H; q.W = W;
+    ProfScope ps(c, st, P_CONV3X3);
+    if (rb.cin == rb.cout) {
+        q.res = x; q.res_bs = x_bs;
+        HIP_TRY(c, lass_launch_conv(CONV2_IDENT, q, st));
+    } else {
+        q.in2 = x; q.in2_bs = x_bs; q.Cin2 = rb.cin; q.w2 = rb.wsc; q.bias = rb.bsc;
+        HIP_TRY(c, lass_launch_conv(CONV2_SHORTCUT, q, st));
+    }
+    return 0;
+}
+
+int run_upconv(lass_ctx* c, int di, const float* x, int B, int h, int w, const float* shift, float* out, long out_bs,
+               hipStream_t st) {
+    const DecSpec& d = kDec[di];
+    const Site& s = c->sites[c->dec_site[di]];
+    ConvArgs p;
+    p.in = x; p.in_bs = (long)d.cin * h * w; p.Cin = d.cin;
+    p.w = rawp(c, std::string("base.") + d.name + ".conv1.weight");  // (cin, cout, uh, uw) == [cin][n], n=(co,a,bb)
+    p.N = p.Nw = d.cout * d.uh * d.uw;
+    p.pro_scale = c->bn_scale + s.off; p.pro_shift = shift + s.off; p.pro_shift_bs = c->n_shift;
+    p.out = out; p.out_bs = out_bs; p.B = B; p.H = h; p.W = w; p.up_h = d.uh;
+    ProfScope ps(c, st, P_TCONV);
+    HIP_TRY(c, lass_launch_conv(TCONV_ACT, p, st));
+    return 0;
+}
+
+// ---- workspace plan ---------------------------------------------------------------------------------------------
+struct Plan {
+    int B, L, T, Tp;
+    size_t total = 0;
+    size_t mag, cosv, sinv, x0, shift, xpre, a2, cat[6], pool[6], center, decout[6], oreal, oimag, frames;
+    int eh[7], ew[7];  // encoder block spatial sizes
+};
+
+size_t bump(size_t& total, size_t floats) {
+    const size_t off = total;
+    total += (floats * sizeof(float) + 255) / 256 * 256;
+    return off;
+}
+
+int make_plan(const lass_ctx* c, int B, int L, Plan* pl) {
+    if (B <= 0 || L <= LASS_NFFT / 2) return LASS_ERR_ARG;
+    pl->B = B; pl->L = L;
+    pl->T = 1 + L / LASS_HOP;
+    pl->Tp = (pl->T + 31) / 32 * 32;
+    size_t& t = pl->total;
+    t = 0;
+    const size_t spec = (size_t)B * pl->T * LASS_NBINS;
+    pl->mag = bump(t, spec); pl->cosv = bump(t, spec); pl->sinv = bump(t, spec);
+    pl->x0 = bump(t, (size_t)B * pl->Tp * LASS_FCROP);
+    pl->shift = bump(t, (size_t)B * c->n_shift);
+    pl->xpre = bump(t, (size_t)B * kPreCh * pl->Tp * LASS_FCROP);
+    int h = pl->Tp, w = LASS_FCROP;
+    size_t a2max = 0;
+    for (int i = 0; i < 7; ++i) {
+        pl->eh[i] = h; pl->ew[i] = w;
+        const size_t o = (size_t)B * kEnc[i].cout * h * w;
+        if (o > a2max) a2max = o;
+        h /= kEnc[i].dh; w /= kEnc[i].dw;
+        if (i < 6) pl->pool[i] = bump(t, (size_t)B * kEnc[i].cout * h * w);
+    }
+    pl->center = bump(t, (size_t)B * kEnc[6].cout * pl->eh[6] * pl->ew[6]);
+    for (int d = 0; d < 6; ++d) {
+        const int e = 5 - d;  // decoder d concatenates the skip of encoder e
+        const size_t hw = (size_t)pl->eh[e] * pl->ew[e];
+        pl->cat[d] = bump(t, (size_t)B * 2 * kDec[d].cout * hw);
+        pl->decout[d] = bump(t, (size_t)B * kDec[d].cout * hw);
+    }
+    pl->a2 = bump(t, a2max);
+    pl->oreal = bump(t, spec); pl->oimag = bump(t, spec);
+    pl->frames = bump(t, (size_t)B * pl->T * LASS_NFFT);
+    return 0;
+}
+
+int check_ready(lass_ctx* c) {
+    if (!c) return LASS_ERR_ARG;
+    if (!c->finalized) return fail(c, LASS_ERR_STATE, "lass_finalize has not been called (or a parameter changed since)");
+    return 0;
+}
+
+const ResBlock* find_block(const lass_ctx* c, const std::string& prefix) {
+    for (const auto& rb : c->enc) if (rb.prefix == prefix) return &rb;
+    for (const auto& rb : c->dec) if (rb.prefix == prefix) return &rb;
+    return nullptr;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lass_version(void) { return 100; }
+
+const char* lass_last_error(const lass_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+int lass_create(lass_ctx** out, int device_id) {
+    if (!out) return LASS_ERR_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        g_create_err = std::string("no HIP device available: ") + hipGetErrorString(e) +
+                       " (liblass_hip has no CPU fallback)";
+        return LASS_ERR_HIP;
+    }
+    if (device_id < 0 || device_id >= ndev) {
+        g_create_err = "device_id out of range";
+        return LASS_ERR_ARG;
+    }
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device_id);
+    if (e != hipSuccess) {
+        g_create_err = std::string("hipGetDeviceProperties: ") + hipGetErrorString(e);
+        return LASS_ERR_HIP;
+    }
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) {
+        g_create_err = std::string("device is ") + prop.gcnArchName + "; liblass_hip is built for gfx950 only";
+        return LASS_ERR_HIP;
+    }
+    lass_ctx* c = new lass_ctx();
+    c->device = device_id;
+    c->prof.resize(P_COUNT);
+    for (int i = 0; i < P_COUNT; ++i) c->prof[i].name = kProfNames[i];
+    build_arch(c);
+    if (hipSetDevice(device_id) != hipSuccess) {
+        g_create_err = "hipSetDevice failed";
+        delete c;
+        return LASS_ERR_HIP;
+    }
+    // FFT twiddles and periodic Hann window, evaluated in double on the host.
+    std::vector<float2> tw(LASS_NFFT);
+    std::vector<float> win(LASS_NFFT);
+    for (int k = 0; k < LASS_NFFT; ++k) {
+        const double a = 2.0 * M_PI * k / LASS_NFFT;
+        tw[k] = make_float2((float)std::cos(a), (float)std::sin(a));
+        win[k] = (float)(0.5 - 0.5 * std::cos(a));
+    }
+    if (hipMalloc((void**)&c->tw, sizeof(float2) * LASS_NFFT) != hipSuccess ||
+        hipMalloc((void**)&c->win, sizeof(float) * LASS_NFFT) != hipSuccess ||
+        hipMemcpy(c->tw, tw.data(), sizeof(float2) * LASS_NFFT, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(c->win, win.data(), sizeof(float) * LASS_NFFT, hipMemcpyHostToDevice) != hipSuccess) {
+        g_create_err = "allocating FFT tables failed";
+        delete c;
+        return LASS_ERR_HIP;
+    }
+    *out = c;
+    return 0;
+}
+
+int lass_destroy(lass_ctx* c) {
+    if (!c) return LASS_ERR_ARG;
+    (void)hipSetDevice(c->device);
+    free_owned(c);
+    for (auto& kv : c->raw) (void)hipFree(kv.second.d);
+    for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    (void)hipFree(c->tw);
+    (void)hipFree(c->win);
+    delete c;
+    return 0;
+}
+
+int lass_set_param(lass_ctx* c, const char* name_c, const void* data, const int64_t* shape, int ndim, int dtype) {
+    if (!c || !name_c || !data || ndim < 0 || (ndim > 0 && !shape)) return fail(c, LASS_ERR_ARG, "bad argument");
+    const std::string name(name_c);
+    std::vector<int64_t> want = expected_shape(c, name);
+    if (want.empty()) {
+        if (ignorable(name)) return 1;
+        return fail(c, LASS_ERR_ARG, "unknown parameter '" + name + "'");
+    }
+    if (dtype != LASS_F32) return fail(c, LASS_ERR_ARG, "parameter '" + name + "' must be float32");
+    std::vector<int64_t> got(shape, shape + ndim);
+    if (got != want) {
+        std::string m = "shape mismatch for '" + name + "': got (";
+        for (auto v : got) m += std::to_string(v) + ",";
+        m += ") want (";
+        for (auto v : want) m += std::to_string(v) + ",";
+        return fail(c, LASS_ERR_ARG, m + ")");
+    }
+    size_t n = 1;
+    for (auto v : want) n *= (size_t)v;
+    HIP_TRY(c, hipSetDevice(c->device));
+    Raw& r = c->raw[name];
+    if (!r.d) HIP_TRY(c, hipMalloc((void**)&r.d, n * sizeof(float)));
+    r.shape = want;
+    r.n = n;
+    HIP_TRY(c, hipMemcpy(r.d, data, n * sizeof(float), hipMemcpyDefault));
+    c->finalized = false;
+    return 0;
+}
+
+int lass_finalize(lass_ctx* c, int compute_mode) {
+    if (!c) return LASS_ERR_ARG;
+    if (compute_mode != LASS_COMPUTE_F32) return fail(c, LASS_ERR_ARG, "unsupported compute mode");
+    HIP_TRY(c, hipSetDevice(c->device));
+    free_owned(c);
+    c->finalized = false;
+    hipStream_t st = nullptr;
+    auto need = [&](const std::string& n) -> const float* {
+        const float* p = rawp(c, n);
+        if (!p && c->err.empty()) c->err = "missing parameter '" + n + "'";
+        return p;
+    };
+    c->err.clear();
+    // -- BN folding for the 32 live sites + bn0, FiLM concatenation
+    if (dev_alloc(c, &c->bn_scale, c->n_shift) || dev_alloc(c, &c->bn_base, c->n_shift) ||
+        dev_alloc(c, &c->film_W, (size_t)c->n_shift * LASS_COND) || dev_alloc(c, &c->film_b, c->n_shift) ||
+        dev_alloc(c, &c->bn0_s, LASS_NBINS) || dev_alloc(c, &c->bn0_h, LASS_NBINS))
+        return LASS_ERR_HIP;
+    for (const auto& s : c->sites) {
+        const float *g = need(s.bn + ".weight"), *b = need(s.bn + ".bias"), *m = need(s.bn + ".running_mean"),
+                    *v = need(s.bn + ".running_var"), *fw = need("film." + s.film + ".weight"),
+                    *fb = need("film." + s.film + ".bias");
+        if (!g || !b || !m || !v || !fw || !fb) return LASS_ERR_STATE;
+        HIP_TRY(c, lass_launch_bnfold(g, b, m, v, s.C, kBnEps, c->bn_scale + s.off, c->bn_base + s.off, st));
+        HIP_TRY(c, hipMemcpyAsync(c->film_W + (size_t)s.off * LASS_COND, fw, (size_t)s.C * LASS_COND * sizeof(float),
+                                  hipMemcpyDeviceToDevice, st));
+        HIP_TRY(c, hipMemcpyAsync(c->film_b + s.off, fb, s.C * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+    {
+        const float *g = need("base.bn0.weight"), *b = need("base.bn0.bias"), *m = need("base.bn0.running_mean"),
+                    *v = need("base.bn0.running_var");
+        if (!g || !b || !m || !v) return LASS_ERR_STATE;
+        HIP_TRY(c, lass_launch_bnfold(g, b, m, v, LASS_NBINS, kBnEps, c->bn0_s, c->bn0_h, st));
+    }
+    if (!need("base.pre_conv.weight") || !need("base.pre_conv.bias") || !need("base.after_conv.weight") ||
+        !need("base.after_conv.bias"))
+        return LASS_ERR_STATE;
+    // -- conv weights -> [cin][tap][cout]
+    auto prep = [&](ResBlock& rb) -> int {
+        const float *w1 = need(rb.prefix + ".conv1.weight"), *w2 = need(rb.prefix + ".conv2.weight");
+        if (!w1 || !w2) return LASS_ERR_STATE;
+        if (dev_alloc(c, &rb.w1, (size_t)rb.cout * rb.cin * 9) || dev_alloc(c, &rb.w2, (size_t)rb.cout * rb.cout * 9))
+            return LASS_ERR_HIP;
+        HIP_TRY(c, lass_launch_relayout_conv(w1, rb.cout, rb.cin, 9, rb.w1, st));
+        HIP_TRY(c, lass_launch_relayout_conv(w2, rb.cout, rb.cout, 9, rb.w2, st));
+        rb.wsc = nullptr;
+        rb.bsc = nullptr;
+        if (rb.cin != rb.cout) {
+            const float *ws = need(rb.prefix + ".shortcut.weight"), *bs = need(rb.prefix + ".shortcut.bias");
+            if (!ws || !bs) return LASS_ERR_STATE;
+            if (dev_alloc(c, &rb.wsc, (size_t)rb.cout * rb.cin)) return LASS_ERR_HIP;
+            HIP_TRY(c, lass_launch_relayout_conv(ws, rb.cout, rb.cin, 1, rb.wsc, st));
+            rb.bsc = bs;
+        }
+        return 0;
+    };
+    for (auto& rb : c->enc) { int r = prep(rb); if (r) return r; }
+    for (auto& rb : c->dec) { int r = prep(rb); if (r) return r; }
+    for (const auto& d : kDec)
+        if (!need(std::string("base.") + d.name + ".conv1.weight")) return LASS_ERR_STATE;
+    HIP_TRY(c, hipStreamSynchronize(st));
+    c->finalized = true;
+    return 0;
+}
+
+int lass_workspace_bytes(const lass_ctx* c, int B, int L, size_t* bytes) {
+    if (!c || !bytes) return LASS_ERR_ARG;
+    Plan pl;
+    if (make_plan(c, B, L, &pl)) return LASS_ERR_ARG;
+    *bytes = pl.total;
+    return 0;
+}
+
+int lass_film_width(const lass_ctx* c) { return c ? c->n_shift : LASS_ERR_ARG; }
+
+int lass_film_offset(const lass_ctx* c, const char* site) {
+    if (!c || !site) return -1;
+    auto it = c->site_idx.find(site);
+    return it == c->site_idx.end() ? -1 : c->sites[it->second].off;
+}
+
+int lass_film(lass_ctx* c, const float* cond, int B, float* shift, void* stream) {
+    int r = check_ready(c);
+    if (r) return r;
+    if (!cond || !shift || B <= 0) return fail(c, LASS_ERR_ARG, "lass_film: bad argument");
+    HIP_TRY(c, lass_launch_film(cond, B, c->film_W, c->film_b, c->bn_base, c->n_shift, shift, (hipStream_t)stream));
+    return 0;
+}
+
+int lass_film_raw(lass_ctx* c, const float* cond, int B, float* film, void* stream) {
+    int r = check_ready(c);
+    if (r) return r;
+    if (!cond || !film || B <= 0) return fail(c, LASS_ERR_ARG, "lass_film_raw: bad argument");
+    HIP_TRY(c, lass_launch_film(cond, B, c->film_W, c->film_b, nullptr, c->n_shift, film, (hipStream_t)stream));
+    return 0;
+}
+
+int lass_stft_magphase(lass_ctx* c, const float* wav, int B, int L, float* mag, float* cos_out, float* sin_out,
+                       float* real_out, float* imag_out, void* stream) {
+    if (!c || !wav || B <= 0 || L <= LASS_NFFT / 2) return fail(c, LASS_ERR_ARG, "lass_stft_magphase: bad argument");
+    const int T = 1 + L / LASS_HOP;
+    HIP_TRY(c, lass_launch_stft(wav, B, L, T, T, c->tw, c->win, mag, cos_out, sin_out, real_out, imag_out, nullptr,
+                                nullptr, nullptr, (hipStream_t)stream));
+    return 0;
+}
+
+int lass_istft(lass_ctx* c, const float* real, const float* imag, int B, int T, int L, float* wav, float* frames_ws,
+               void* stream) {
+    if (!c || !real || !imag || !wav || !frames_ws || B <= 0 || T <= 0 || L <= 0 ||
+        (long)L + LASS_NFFT / 2 > (long)(T - 1) * LASS_HOP + LASS_NFFT)
+        return fail(c, LASS_ERR_ARG, "lass_istft: bad argument");
+    HIP_TRY(c, lass_launch_istft_frames(real, imag, B, T, c->tw, c->win, frames_ws, (hipStream_t)stream));
+    HIP_TRY(c, lass_launch_istft_ola(frames_ws, B, T, L, c->win, wav, (hipStream_t)stream));
+    return 0;
+}
+
+int lass_convblock(lass_ctx* c, const char* prefix, const float* x, int B, int H, int W, const float* shift, float* y,
+                   float* scratch, void* stream) {
+    int r = check_ready(c);
+    if (r) return r;
+    if (!prefix || !x || !shift || !y || !scratch) return fail(c, LASS_ERR_ARG, "lass_convblock: bad argument");
+    const ResBlock* rb = find_block(c, prefix);
+    if (!rb) return fail(c, LASS_ERR_ARG, std::string("lass_convblock: unknown block '") + prefix + "'");
+    const long HW = (long)H * W;
+    return run_resblock(c, *rb, x, rb->cin * HW, B, H, W, shift, scratch, y, rb->cout * HW, (hipStream_t)stream);
+}
+
+int lass_upconv(lass_ctx* c, const char* name, const float* x, int B, int h, int w, const float* shift, float* y,
+                void* stream) {
+    int r = check_ready(c);
+    if (r) return r;
+    if (!name || !x || !shift || !y) return fail(c, LASS_ERR_ARG, "lass_upconv: bad argument");
+    for (int i = 0; i < 6; ++i)
+        if (std::string("base.") + kDec[i].name == name)
+            return run_upconv(c, i, x, B, h, w, shift, y, (long)kDec[i].cout * h * kDec[i].uh * w * kDec[i].uw,
+                              (hipStream_t)stream);
+    return fail(c, LASS_ERR_ARG, std::string("lass_upconv: unknown decoder '") + name + "'");
+}
+
+int lass_mask_apply(lass_ctx* c, const float* x12, const float* mag, const float* cos_in, const float* sin_in, int B,
+                    int T, int Tpad, float* out_real, float* out_imag, void* stream) {
+    int r = check_ready(c);
+    if (r) return r;
+    if (!x12 || !mag || !cos_in || !sin_in || !out_real || !out_imag)
+        return fail(c, LASS_ERR_ARG, "lass_mask_apply: bad argument");
+    HIP_TRY(c, lass_launch_mask(x12, rawp(c, "base.after_conv.weight"), rawp(c, "base.after_conv.bias"), mag, cos_in,
+                                sin_in, B, T, Tpad, out_real, out_imag, (hipStream_t)stream));
+    return 0;
+}
+
+int lass_sdr_stats(lass_ctx* c, const float* ref, const float* est, int B, int L, double* stats, void* stream) {
+    if (!c || !ref || !est || !stats || B <= 0 || L <= 0) return fail(c, LASS_ERR_ARG, "lass_sdr_stats: bad argument");
+    HIP_TRY(c, lass_launch_sdr(ref, est, B, L, stats, (hipStream_t)stream));
+    return 0;
+}
+
+int lass_separate(lass_ctx* c, const float* mixture, const float* condition, float* out, int B, int L, void* workspace,
+                  size_t workspace_bytes, void* stream) {
+    int r = check_ready(c);
+    if (r) return r;
+    if (!mixture || !condition || !out || !workspace) return fail(c, LASS_ERR_ARG, "lass_separate: null pointer");
+    Plan pl;
+    if (make_plan(c, B, L, &pl)) return fail(c, LASS_ERR_ARG, "lass_separate: need B >= 1 and L > 512");
+    if (workspace_bytes < pl.total)
+        return fail(c, LASS_ERR_WORKSPACE, "workspace too small: need " + std::to_string(pl.total) + " bytes");
+    if (((uintptr_t)workspace & 255) != 0) return fail(c, LASS_ERR_ARG, "workspace must be 256-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    auto F = [&](size_t off) { return (float*)(ws + off); };
+    const int T = pl.T, Tp = pl.Tp;
+    float* shift = F(pl.shift);
+    {
+        ProfScope ps(c, st, P_STFT);
+        HIP_TRY(c, lass_launch_stft(mixture, B, L, T, Tp, c->tw, c->win, F(pl.mag), F(pl.cosv), F(pl.sinv), nullptr,
+                                    nullptr, F(pl.x0), c->bn0_s, c->bn0_h, st));
+    }
+    {
+        ProfScope ps(c, st, P_FILM);
+        HIP_TRY(c, lass_launch_film(condition, B, c->film_W, c->film_b, c->bn_base, c->n_shift, shift, st));
+    }
+    {
+        ProfScope ps(c, st, P_PRECONV);
+        HIP_TRY(c, lass_launch_preconv(F(pl.x0), rawp(c, "base.pre_conv.weight"), rawp(c, "base.pre_conv.bias"), B,
+                                       kPreCh, (long)Tp * LASS_FCROP, F(pl.xpre), st));
+    }
+    // ---- encoder (resunet.py:556-562) -------------------------------------------------------------------------
+    const float* x = F(pl.xpre);
+    for (int i = 0; i < 7; ++i) {
+        const int H = pl.eh[i], W = pl.ew[i];
+        const long HW = (long)H * W;
+        const ResBlock& rb = c->enc[i];
+        float* o;
+        long o_bs;
+        if (i < 6) {  // skip output lives in the second channel half of decoder (5-i)'s concat buffer
+            o = F(pl.cat[5 - i]) + (size_t)rb.cout * HW;
+            o_bs = 2 * rb.cout * HW;
+        } else {
+            o = F(pl.center);
+            o_bs = rb.cout * HW;
+        }
+        r = run_resblock(c, rb, x, rb.cin * HW, B, H, W, shift, F(pl.a2), o, o_bs, st);
+        if (r) return r;
+        if (i < 6) {
+            ProfScope ps(c, st, P_POOL);
+            HIP_TRY(c, lass_launch_pool(o, o_bs, B, rb.cout, H, W, kEnc[i].dh, kEnc[i].dw, F(pl.pool[i]), st));
+            x = F(pl.pool[i]);
+        } else {
+            x = o;  // downsample (1,1) is the identity (resunet.py:363-370)
+        }
+    }
+    // ---- decoder (resunet.py:563-568) -------------------------------------------------------------------------
+    for (int d = 0; d < 6; ++d) {
+        const int e = 5 - d;
+        const int H = pl.eh[e], W = pl.ew[e];
+        const long HW = (long)H * W;
+        const int h = H / kDec[d].uh, w = W / kDec[d].uw;
+        const ResBlock& rb = c->dec[d];
+        r = run_upconv(c, d, x, B, h, w, shift, F(pl.cat[d]), 2 * rb.cout * HW, st);
+        if (r) return r;
+        r = run_resblock(c, rb, F(pl.cat[d]), 2 * rb.cout * HW, B, H, W, shift, F(pl.a2), F(pl.decout[d]),
+                         rb.cout * HW, st);
+        if (r) return r;
+        x = F(pl.decout[d]);
+    }
+    {
+        ProfScope ps(c, st, P_MASK);
+        HIP_TRY(c, lass_launch_mask(x, rawp(c, "base.after_conv.weight"), rawp(c, "base.after_conv.bias"), F(pl.mag),
+                                    F(pl.cosv), F(pl.sinv), B, T, Tp, F(pl.oreal), F(pl.oimag), st));
+    }
+    {
+        ProfScope ps(c, st, P_ISTFT);
+        HIP_TRY(c, lass_launch_istft_frames(F(pl.oreal), F(pl.oimag), B, T, c->tw, c->win, F(pl.frames), st));
+        HIP_TRY(c, lass_launch_istft_ola(F(pl.frames), B, T, L, c->win, out, st));
+    }
+    return 0;
+}
+
+int lass_set_profiling(lass_ctx* c, int enabled) {
+    if (!c) return LASS_ERR_ARG;
+    c->profiling = enabled != 0;
+    return 0;
+}
+int lass_profile_count(const lass_ctx* c) { return c ? P_COUNT : LASS_ERR_ARG; }
+int lass_profile_get(lass_ctx* c, int i, const char** name, double* ms, int* launches) {
+    if (!c || i < 0 || i >= P_COUNT) return LASS_ERR_ARG;
+    prof_collect(c);
+    if (name) *name = c->prof[i].name;
+    if (ms) *ms = c->prof[i].ms;
+    if (launches) *launches = c->prof[i].launches;
+    return 0;
+}
+int lass_profile_reset(lass_ctx* c) {
+    if (!c) return LASS_ERR_ARG;
+    prof_collect(c);
+    for (auto& p : c->prof) { p.ms = 0; p.launches = 0; }
+    return 0;
+}
+
+}  // extern "C"

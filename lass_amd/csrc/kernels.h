@@ -1,0 +1,76 @@
+// kernels.h - internal launch interfaces between the C-ABI layer (api.hip) and the kernel translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+constexpr int LASS_NFFT = 1024;
+constexpr int LASS_HOP = 160;
+constexpr int LASS_NBINS = 513;
+constexpr int LASS_FCROP = 512;
+constexpr int LASS_COND = 512;
+
+// ---- conv.hip -----------------------------------------------------------------------------------------------------
+struct ConvArgs {
+    // phase A: K = Cin x TAPS
+    const float* in = nullptr;  // (B, Cin, H, W); batch stride in_bs, channel stride H*W
+    long in_bs = 0;
+    int Cin = 0;
+    const float* w = nullptr;  // Wt[Cin][TAPS][Nw]
+    int Nw = 0;                // row pitch of the weight matrix (total output channels it holds)
+    const float* pro_scale = nullptr;  // [Cin]
+    const float* pro_shift = nullptr;  // [B][pro_shift_bs], column = channel
+    int pro_shift_bs = 0;
+    // phase B: 1x1 shortcut over the raw block input
+    const float* in2 = nullptr;
+    long in2_bs = 0;
+    int Cin2 = 0;
+    const float* w2 = nullptr;    // [Cin2][Nw]
+    const float* bias = nullptr;  // [Nw]
+    const float* res = nullptr;   // (B, N, H, W) residual
+    long res_bs = 0;
+    const float* epi_scale = nullptr;  // [N]
+    const float* epi_shift = nullptr;  // [B][epi_shift_bs]
+    int epi_shift_bs = 0;
+    float* out = nullptr;
+    long out_bs = 0;
+    int B = 0, H = 0, W = 0;
+    int N = 0;  // output channels computed by this launch (GEMM rows)
+    int up_h = 1;  // TCONV: vertical stride (1 or 2); horizontal stride is always 2
+};
+
+enum ConvKind { CONV1_ACT = 0, CONV2_IDENT = 1, CONV2_SHORTCUT = 2, TCONV_ACT = 3 };
+
+hipError_t lass_launch_conv(ConvKind kind, const ConvArgs& p, hipStream_t stream);
+
+// ---- stft.hip -----------------------------------------------------------------------------------------------------
+// tw: 1024 float2 (cos, sin)(2*pi*k/1024); win: 1024 floats (periodic Hann)
+// Writes mag/cos/sin/real/imag (B,T,513) where non-null and, when x0 != null, the bn0-normalised, T-padded, F-cropped
+// network input x0 (B,Tpad,512) = mag*s0[f] + h0[f] for t < T, 0 for T <= t < Tpad.
+hipError_t lass_launch_stft(const float* wav, int B, int L, int T, int Tpad, const float2* tw, const float* win,
+                            float* mag, float* cosv, float* sinv, float* real, float* imag, float* x0,
+                            const float* s0, const float* h0, hipStream_t stream);
+hipError_t lass_launch_istft_frames(const float* real, const float* imag, int B, int T, const float2* tw,
+                                    const float* win, float* frames, hipStream_t stream);
+hipError_t lass_launch_istft_ola(const float* frames, int B, int T, int L, const float* win, float* wav,
+                                 hipStream_t stream);
+
+// ---- misc.hip -----------------------------------------------------------------------------------------------------
+// film[b][j] = dot(cond[b], Wf[j]) + bf[j] (+ base[j] if base)   for j < n
+hipError_t lass_launch_film(const float* cond, int B, const float* Wf, const float* bf, const float* base, int n,
+                            float* out, hipStream_t stream);
+// out[b][c][t][f] = w[c]*x0[b][t][f] + bias[c]
+hipError_t lass_launch_preconv(const float* x0, const float* w, const float* bias, int B, int C, long HW, float* out,
+                               hipStream_t stream);
+// average pool (ph x pw) of (B,C,H,W) with batch stride in_bs -> (B,C,H/ph,W/pw) dense
+hipError_t lass_launch_pool(const float* in, long in_bs, int B, int C, int H, int W, int ph, int pw, float* out,
+                            hipStream_t stream);
+hipError_t lass_launch_mask(const float* x12, const float* wa, const float* ba, const float* mag, const float* cosv,
+                            const float* sinv, int B, int T, int Tpad, float* out_real, float* out_imag,
+                            hipStream_t stream);
+hipError_t lass_launch_sdr(const float* ref, const float* est, int B, int L, double* stats, hipStream_t stream);
+// dst[ci][tap][co] = src[co][ci][tap]
+hipError_t lass_launch_relayout_conv(const float* src, int Cout, int Cin, int taps, float* dst, hipStream_t stream);
+// scale[c] = g/sqrt(var+eps); base[c] = beta - mean*scale
+hipError_t lass_launch_bnfold(const float* g, const float* beta, const float* mean, const float* var, int C, float eps,
+                              float* scale, float* base, hipStream_t stream);

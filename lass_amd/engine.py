@@ -1,0 +1,219 @@
+"""Thin torch-tensor front end over the C-ABI: owns one `lass_ctx`, hands device pointers and the current HIP stream
+to liblass_hip.  torch is plumbing here (device memory, streams); every number is produced by the HIP kernels."""
+from __future__ import annotations
+
+import ctypes
+from ctypes import byref, c_char_p, c_double, c_int, c_int64, c_size_t, c_void_p
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib, arch
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+
+
+def _stream(device) -> c_void_p:
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class Engine:
+    """One context per (process, device)."""
+
+    def __init__(self, device="cuda:0"):
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.LassError("lass_amd computes on an MI355X only (device must be a cuda/HIP device)")
+        if not torch.cuda.is_available():
+            raise _lib.LassError("no HIP device visible to torch; lass_amd has no CPU fallback")
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", idx)
+        h = c_void_p()
+        rc = self.lib.lass_create(byref(h), idx)
+        if rc < 0:
+            raise _lib.LassError(f"lass_create failed ({rc}): {self.lib.lass_last_error(None).decode()}")
+        self.ctx = h
+        self._ws: Dict[tuple, torch.Tensor] = {}
+        self.finalized = False
+
+    def __del__(self):
+        try:
+            if getattr(self, "ctx", None):
+                self.lib.lass_destroy(self.ctx)
+                self.ctx = None
+        except Exception:
+            pass
+
+    # ---- weights ---------------------------------------------------------------------------------------------
+    def set_param(self, name: str, t) -> int:
+        if isinstance(t, np.ndarray):
+            t = torch.from_numpy(np.ascontiguousarray(t))
+        t = t.detach()
+        if not t.is_floating_point():
+            return 1  # num_batches_tracked & co: not used by inference
+        t = t.to(torch.float32).contiguous()
+        shape = (c_int64 * max(1, t.dim()))(*t.shape)
+        rc = self.lib.lass_set_param(self.ctx, name.encode(), _ptr(t), shape, t.dim(), 0)
+        if t.is_cuda:
+            torch.cuda.current_stream(t.device).synchronize()
+        self.finalized = False
+        return _lib.check(self.ctx, rc, f"lass_set_param({name})")
+
+    def load_state_dict(self, sd: Dict[str, object]):
+        for k, v in sd.items():
+            self.set_param(k, v)
+        self.finalize()
+
+    def finalize(self):
+        _lib.check(self.ctx, self.lib.lass_finalize(self.ctx, 0), "lass_finalize")
+        self.finalized = True
+
+    # ---- hot path --------------------------------------------------------------------------------------------
+    def workspace_bytes(self, B: int, L: int) -> int:
+        n = c_size_t()
+        _lib.check(self.ctx, self.lib.lass_workspace_bytes(self.ctx, B, L, byref(n)), "lass_workspace_bytes")
+        return n.value
+
+    def _workspace(self, B: int, L: int) -> torch.Tensor:
+        key = (B, L)
+        ws = self._ws.get(key)
+        if ws is None:
+            self._ws.clear()  # one live shape at a time: workspaces are GBs
+            ws = torch.empty(self.workspace_bytes(B, L), dtype=torch.uint8, device=self.device)
+            self._ws[key] = ws
+        return ws
+
+    def separate(self, mixture: torch.Tensor, condition: torch.Tensor, out: Optional[torch.Tensor] = None):
+        """mixture (B,L) f32, condition (B,512) f32 on this device -> (B,L) f32."""
+        assert mixture.dim() == 2 and condition.dim() == 2 and condition.shape == (mixture.shape[0], arch_cond())
+        mixture = self._dev(mixture)
+        condition = self._dev(condition)
+        B, L = mixture.shape
+        if out is None:
+            out = torch.empty_like(mixture)
+        ws = self._workspace(B, L)
+        rc = self.lib.lass_separate(self.ctx, _ptr(mixture), _ptr(condition), _ptr(out), B, L, _ptr(ws), ws.numel(),
+                                    _stream(self.device))
+        _lib.check(self.ctx, rc, "lass_separate")
+        return out
+
+    def _dev(self, t: torch.Tensor) -> torch.Tensor:
+        if t.device != self.device:
+            raise _lib.LassError(f"tensor on {t.device}, engine on {self.device}")
+        if t.dtype != torch.float32:
+            raise _lib.LassError("float32 tensors only")
+        return t.contiguous()
+
+    # ---- stage entry points (parity tests) -------------------------------------------------------------------
+    def stft_magphase(self, wav: torch.Tensor, want_complex: bool = False):
+        wav = self._dev(wav)
+        B, L = wav.shape
+        T = arch.frames_for(L)
+        mk = lambda: torch.empty(B, T, arch.N_BINS, dtype=torch.float32, device=self.device)  # noqa: E731
+        mag, cos, sin = mk(), mk(), mk()
+        re, im = (mk(), mk()) if want_complex else (None, None)
+        rc = self.lib.lass_stft_magphase(self.ctx, _ptr(wav), B, L, _ptr(mag), _ptr(cos), _ptr(sin), _ptr(re),
+                                         _ptr(im), _stream(self.device))
+        _lib.check(self.ctx, rc, "lass_stft_magphase")
+        return (mag, cos, sin, re, im) if want_complex else (mag, cos, sin)
+
+    def istft(self, real: torch.Tensor, imag: torch.Tensor, length: int):
+        real, imag = self._dev(real), self._dev(imag)
+        B, T, F = real.shape
+        assert F == arch.N_BINS and imag.shape == real.shape
+        wav = torch.empty(B, length, dtype=torch.float32, device=self.device)
+        frames = torch.empty(B, T, arch.N_FFT, dtype=torch.float32, device=self.device)
+        rc = self.lib.lass_istft(self.ctx, _ptr(real), _ptr(imag), B, T, length, _ptr(wav), _ptr(frames),
+                                 _stream(self.device))
+        _lib.check(self.ctx, rc, "lass_istft")
+        return wav
+
+    def film_width(self) -> int:
+        return self.lib.lass_film_width(self.ctx)
+
+    def film_offset(self, site: str) -> int:
+        return self.lib.lass_film_offset(self.ctx, site.encode())
+
+    def film(self, cond: torch.Tensor, raw: bool = False) -> torch.Tensor:
+        cond = self._dev(cond)
+        B = cond.shape[0]
+        out = torch.empty(B, self.film_width(), dtype=torch.float32, device=self.device)
+        fn = self.lib.lass_film_raw if raw else self.lib.lass_film
+        _lib.check(self.ctx, fn(self.ctx, _ptr(cond), B, _ptr(out), _stream(self.device)), "lass_film")
+        return out
+
+    def convblock(self, prefix: str, x: torch.Tensor, shift: torch.Tensor, cout: int) -> torch.Tensor:
+        x = self._dev(x)
+        B, _cin, H, W = x.shape
+        y = torch.empty(B, cout, H, W, dtype=torch.float32, device=self.device)
+        scratch = torch.empty_like(y)
+        rc = self.lib.lass_convblock(self.ctx, prefix.encode(), _ptr(x), B, H, W, _ptr(shift), _ptr(y), _ptr(scratch),
+                                     _stream(self.device))
+        _lib.check(self.ctx, rc, "lass_convblock")
+        return y
+
+    def upconv(self, name: str, x: torch.Tensor, shift: torch.Tensor, cout: int, up) -> torch.Tensor:
+        x = self._dev(x)
+        B, _cin, h, w = x.shape
+        y = torch.empty(B, cout, h * up[0], w * up[1], dtype=torch.float32, device=self.device)
+        rc = self.lib.lass_upconv(self.ctx, name.encode(), _ptr(x), B, h, w, _ptr(shift), _ptr(y),
+                                  _stream(self.device))
+        _lib.check(self.ctx, rc, "lass_upconv")
+        return y
+
+    def mask_apply(self, x12, mag, cos, sin):
+        x12, mag, cos, sin = map(self._dev, (x12, mag, cos, sin))
+        B, C, Tp, F = x12.shape
+        T = mag.shape[1]
+        assert C == 32 and F == arch.F_CROP
+        o_re = torch.empty_like(mag)
+        o_im = torch.empty_like(mag)
+        rc = self.lib.lass_mask_apply(self.ctx, _ptr(x12), _ptr(mag), _ptr(cos), _ptr(sin), B, T, Tp, _ptr(o_re),
+                                      _ptr(o_im), _stream(self.device))
+        _lib.check(self.ctx, rc, "lass_mask_apply")
+        return o_re, o_im
+
+    def sdr_stats(self, ref: torch.Tensor, est: torch.Tensor) -> torch.Tensor:
+        """(B,L),(B,L) f32 -> (B,6) f64 sums (see include/lass_hip.h)."""
+        ref, est = self._dev(ref), self._dev(est)
+        B, L = ref.shape
+        stats = torch.empty(B, 6, dtype=torch.float64, device=self.device)
+        rc = self.lib.lass_sdr_stats(self.ctx, _ptr(ref), _ptr(est), B, L, _ptr(stats), _stream(self.device))
+        _lib.check(self.ctx, rc, "lass_sdr_stats")
+        return stats
+
+    # ---- instrumentation -------------------------------------------------------------------------------------
+    def set_profiling(self, on: bool):
+        self.lib.lass_set_profiling(self.ctx, 1 if on else 0)
+
+    def profile(self, reset: bool = True) -> Dict[str, tuple]:
+        """{kernel class: (ms, launches)} accumulated since the last reset.  Caller must have synchronised."""
+        out = {}
+        for i in range(self.lib.lass_profile_count(self.ctx)):
+            name, ms, n = c_char_p(), c_double(), c_int()
+            self.lib.lass_profile_get(self.ctx, i, byref(name), byref(ms), byref(n))
+            out[name.value.decode()] = (ms.value, n.value)
+        if reset:
+            self.lib.lass_profile_reset(self.ctx)
+        return out
+
+
+def arch_cond() -> int:
+    return 512
+
+
+_ENGINES: Dict[int, Engine] = {}
+
+
+def get_engine(device) -> Engine:
+    """Process-wide engine for a device (weights are per ResUNet30 instance -> each model owns its own Engine;
+    this shared one serves weight-free ops: STFT, iSTFT, SDR statistics)."""
+    device = torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _ENGINES:
+        _ENGINES[idx] = Engine(torch.device("cuda", idx))
+    return _ENGINES[idx]

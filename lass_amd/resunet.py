@@ -1,0 +1,151 @@
+"""Host-side mirror of the reference separator interface (drop-in for /root/reference/models/resunet.py:621-714).
+
+`ResUNet30(input_channels, output_channels, condition_size)` is an nn.Module whose state_dict keys, shapes and init
+are the reference's, so reference checkpoints load unchanged; `forward(input_dict) -> {'waveform': (B,1,L)}` and
+`chunk_inference(input_dict) -> ndarray (1,L) float64` keep the reference signatures.  The module holds parameters
+only - all arithmetic happens in liblass_hip (HIP kernels, include/lass_hip.h).  Inference (eval mode) only:
+BatchNorm uses running statistics (dcase_evaluator.py:57).
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import arch
+from ._lib import LassError
+from .engine import Engine
+
+_IGNORED_PREFIXES = ("base.stft.", "base.istft.")  # torchlibrosa's frozen DFT buffers in reference checkpoints
+
+
+class _Holder(nn.Module):
+    """Parameter container; the tree of these reproduces the reference's module names."""
+
+
+def _init_tensor(kind: str, shape) -> torch.Tensor:
+    """Reference initialisation: models/base.py:9-21 (xavier_uniform weights, zero bias; BN gamma=1, beta=0)."""
+    if kind in ("conv_w", "tconv_w", "linear_w"):
+        t = torch.empty(*shape)
+        nn.init.xavier_uniform_(t)
+        return t
+    if kind in ("bias", "linear_b", "bn_bias", "bn_mean"):
+        return torch.zeros(*shape)
+    if kind in ("bn_weight", "bn_var"):
+        return torch.ones(*shape)
+    if kind == "bn_nbt":
+        return torch.tensor(0, dtype=torch.long)
+    raise ValueError(kind)
+
+
+class ResUNet30(nn.Module):
+    def __init__(self, input_channels: int = 1, output_channels: int = 1, condition_size: int = 512):
+        super().__init__()
+        if (input_channels, output_channels, condition_size) != (1, 1, 512):
+            # config/audiosep_base.yaml:23-30 is the only configuration the reference ships or evaluates
+            raise NotImplementedError("lass_amd.ResUNet30 supports input_channels=1, output_channels=1, "
+                                      "condition_size=512 (config/audiosep_base.yaml)")
+        self.input_channels, self.output_channels, self.condition_size = input_channels, output_channels, condition_size
+        self.film_meta = self._film_meta()
+        for name, shape, kind in arch.param_specs(input_channels, output_channels, condition_size):
+            parts = name.split(".")
+            mod: nn.Module = self
+            for p in parts[:-1]:
+                if p not in mod._modules:
+                    mod.add_module(p, _Holder())
+                mod = mod._modules[p]
+            t = _init_tensor(kind, shape)
+            if kind in ("bn_mean", "bn_var", "bn_nbt"):
+                mod.register_buffer(parts[-1], t)
+            else:
+                mod.register_parameter(parts[-1], nn.Parameter(t, requires_grad=False))
+        self._engine: Optional[Engine] = None
+        self._uploaded_sig = None
+        self.eval()
+
+    @staticmethod
+    def _film_meta() -> Dict:
+        """Nested {module: {'beta1': C, 'beta2': C}} as get_film_meta returns (resunet.py:598-618)."""
+        meta: Dict = {}
+        for site, c, _used in arch.film_sites():
+            d = meta
+            parts = site.split("->")
+            for p in parts[:-1]:
+                d = d.setdefault(p, {})
+            d[parts[-1]] = c
+        return meta
+
+    # ---- state handling ------------------------------------------------------------------------------------------
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        sd = {k: v for k, v in state_dict.items() if not k.startswith(_IGNORED_PREFIXES)}
+        r = super().load_state_dict(sd, strict=strict, **kw)
+        self._uploaded_sig = None
+        return r
+
+    def _signature(self):
+        return tuple((t.data_ptr(), t._version) for t in self.state_dict(keep_vars=True).values())
+
+    def _device(self) -> torch.device:
+        return self.base.pre_conv.weight.device
+
+    def _ensure_engine(self) -> Engine:
+        dev = self._device()
+        if dev.type != "cuda":
+            raise LassError("lass_amd.ResUNet30 computes on an MI355X only: move the module with .to('cuda'). "
+                            "There is no CPU fallback.")
+        if self._engine is None or self._engine.device != dev:
+            self._engine = Engine(dev)
+            self._uploaded_sig = None
+        sig = self._signature()
+        if sig != self._uploaded_sig:
+            self._engine.load_state_dict({k: v for k, v in self.state_dict().items()})
+            self._uploaded_sig = sig
+        return self._engine
+
+    @property
+    def engine(self) -> Engine:
+        return self._ensure_engine()
+
+    # ---- reference interface -------------------------------------------------------------------------------------
+    def _separate(self, mixtures: torch.Tensor, conditions: torch.Tensor) -> torch.Tensor:
+        if self.training:
+            raise LassError("lass_amd.ResUNet30 is inference-only (call .eval()); training is out of scope")
+        if mixtures.dim() != 3 or mixtures.shape[1] != 1:
+            raise ValueError("mixture must be (batch_size, 1, segment_samples)")
+        eng = self._ensure_engine()
+        dev = eng.device
+        mix = mixtures.to(device=dev, dtype=torch.float32)[:, 0, :].contiguous()
+        cond = conditions.to(device=dev, dtype=torch.float32).contiguous()
+        return eng.separate(mix, cond)[:, None, :]
+
+    @torch.no_grad()
+    def forward(self, input_dict: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """resunet.py:640-653."""
+        return {"waveform": self._separate(input_dict["mixture"], input_dict["condition"])}
+
+    @torch.no_grad()
+    def chunk_inference(self, input_dict: Dict[str, torch.Tensor]) -> np.ndarray:
+        """resunet.py:655-714, including its quirks: RATE hard-coded to 32000, batch 1, float64 result, zeros when
+        the input is not longer than one window.  The reference runs a second, overlapping forward inside each loop
+        iteration whose write is overwritten by the next iteration except at the tail; the same writes are made here,
+        so outputs are identical sample for sample."""
+        mixtures, conditions = input_dict["mixture"], input_dict["condition"]
+        rate = 32000
+        nl, nc, nr = int(1.0 * rate), int(3.0 * rate), int(1.0 * rate)
+        length = mixtures.shape[2]
+        out_np = np.zeros([1, length])
+        window = nl + nc + nr
+        idx = 0
+        while idx + window < length:
+            c = self._separate(mixtures[:, :, idx:idx + window], conditions).squeeze(0).cpu().numpy()
+            if idx == 0:
+                out_np[:, idx:idx + window - nr] = c[:, :-nr]
+            else:
+                out_np[:, idx + nl:idx + window - nr] = c[:, nl:-nr]
+            idx += nc
+            if idx < length:
+                c = self._separate(mixtures[:, :, idx:idx + window], conditions).squeeze(0).cpu().numpy()
+                out_np[:, idx + nl:idx + c.shape[1]] = c[:, nl:]
+        return out_np

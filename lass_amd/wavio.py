@@ -1,0 +1,64 @@
+"""Minimal RIFF/WAVE reader-writer (PCM16, PCM32, float32), mono down-mix.
+
+Stands in for `librosa.load(path, sr=16000, mono=True)` (dcase_evaluator.py:73-74) for files that are ALREADY at the
+target rate: the DCASE validation audio is distributed at 16 kHz mono (scripts/process_audio.sh: `sox -r 16000 -c 1`),
+so the load reduces to PCM decode + int->float scaling (x/32768 for int16, as soundfile/librosa do).  Resampling is
+not implemented - a rate mismatch raises.
+"""
+from __future__ import annotations
+
+import struct
+
+import numpy as np
+
+
+def read_wav(path: str, sr: int | None = None) -> tuple[np.ndarray, int]:
+    with open(path, "rb") as f:
+        data = f.read()
+    if data[:4] != b"RIFF" or data[8:12] != b"WAVE":
+        raise ValueError(f"{path}: not a RIFF/WAVE file")
+    pos, fmt, raw = 12, None, None
+    while pos + 8 <= len(data):
+        cid, size = data[pos:pos + 4], struct.unpack("<I", data[pos + 4:pos + 8])[0]
+        body = data[pos + 8:pos + 8 + size]
+        if cid == b"fmt ":
+            fmt = struct.unpack("<HHIIHH", body[:16])
+        elif cid == b"data":
+            raw = body
+        pos += 8 + size + (size & 1)
+    if fmt is None or raw is None:
+        raise ValueError(f"{path}: missing fmt/data chunk")
+    tag, ch, rate, _, _, bits = fmt
+    if tag == 0xFFFE and len(data) > 0:  # WAVE_FORMAT_EXTENSIBLE: sub-format in the extension; infer from bits
+        tag = 3 if bits == 32 and b"\x03\x00\x00\x00\x00\x00\x10\x00" in data[:128] else 1
+    if tag == 1 and bits == 16:
+        x = np.frombuffer(raw, dtype="<i2").astype(np.float32) / 32768.0
+    elif tag == 1 and bits == 32:
+        x = (np.frombuffer(raw, dtype="<i4").astype(np.float64) / 2147483648.0).astype(np.float32)
+    elif tag == 3 and bits == 32:
+        x = np.frombuffer(raw, dtype="<f4").astype(np.float32)
+    else:
+        raise ValueError(f"{path}: unsupported WAV encoding tag={tag} bits={bits}")
+    if ch > 1:
+        x = x.reshape(-1, ch).mean(axis=1).astype(np.float32)  # librosa mono=True
+    if sr is not None and rate != sr:
+        raise ValueError(f"{path}: sample rate {rate} != {sr}; resample offline (scripts/process_audio.sh)")
+    return np.ascontiguousarray(x), rate
+
+
+def write_wav_f32(path: str, x: np.ndarray, sr: int) -> None:
+    x = np.ascontiguousarray(x, dtype="<f4")
+    body = x.tobytes()
+    hdr = b"RIFF" + struct.pack("<I", 36 + len(body)) + b"WAVE" + b"fmt " + struct.pack(
+        "<IHHIIHH", 16, 3, 1, sr, sr * 4, 4, 32) + b"data" + struct.pack("<I", len(body))
+    with open(path, "wb") as f:
+        f.write(hdr + body)
+
+
+def write_wav_pcm16(path: str, x: np.ndarray, sr: int) -> None:
+    q = np.clip(np.round(np.asarray(x, dtype=np.float64) * 32768.0), -32768, 32767).astype("<i2")
+    body = q.tobytes()
+    hdr = b"RIFF" + struct.pack("<I", 36 + len(body)) + b"WAVE" + b"fmt " + struct.pack(
+        "<IHHIIHH", 16, 1, 1, sr, sr * 2, 2, 16) + b"data" + struct.pack("<I", len(body))
+    with open(path, "wb") as f:
+        f.write(hdr + body)

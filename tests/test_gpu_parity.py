@@ -1,0 +1,307 @@
+"""GPU parity tests: every HIP stage and the whole hot path, through the C-ABI, against the CPU oracle and the golden
+fixtures (which were produced by the reference's own resunet.py).  Tolerances are absolute float32 figures stated per
+test; the north_star bar for the waveform is 1e-4 RMS."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from lass_amd import arch, synthetic
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _rms(a):
+    return float(torch.as_tensor(a).double().pow(2).mean().sqrt())
+
+
+def _relerr(got, ref):
+    got, ref = torch.as_tensor(got).double().cpu(), torch.as_tensor(ref).double().cpu()
+    return _rms(got - ref) / max(_rms(ref), 1e-30)
+
+
+@pytest.fixture(scope="module")
+def oracle_sd(synthetic_sd):
+    from oracle import resunet as orr
+    return orr.to_torch(synthetic_sd)
+
+
+@pytest.fixture(scope="module")
+def eng(synthetic_sd):
+    from lass_amd.engine import Engine
+    e = Engine(DEV)
+    e.load_state_dict(synthetic_sd)
+    return e
+
+
+@pytest.fixture(scope="module")
+def model(synthetic_sd):
+    from lass_amd.resunet import ResUNet30
+    m = ResUNet30(1, 1, 512)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synthetic_sd.items()})
+    return m.to(DEV).eval()
+
+
+def test_library_loaded_is_in_tree():
+    from lass_amd import _lib
+    lib = _lib.load()
+    assert os.path.samefile(lib._name, _lib.LIB_PATH)
+    maps = open("/proc/self/maps").read()
+    assert "liblass_hip.so" in maps
+
+
+# ---- STFT / iSTFT ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("L", [16000, 160000, 8000 + 77])
+def test_stft_magphase_vs_oracle(eng, L):
+    from oracle import stft as ost
+    g = torch.Generator().manual_seed(L)
+    x = (torch.rand(3, L, generator=g) * 2 - 1) * 0.5
+    x[1] = torch.from_numpy(synthetic.make_mixtures(1, L)[1][0])
+    x[2, : L // 2] = 0.0  # silence: exercises the 1e-10 clamp (cos = sin = 0, mag = 1e-5)
+    mag, cos, sin, re, im = eng.stft_magphase(x.to(DEV), want_complex=True)
+    r64, i64 = ost.stft_fft(x.double())
+    scale = float(r64.abs().max())
+    assert float((re.cpu().double() - r64[:, 0]).abs().max()) < 2e-6 * scale + 1e-6
+    assert float((im.cpu().double() - i64[:, 0]).abs().max()) < 2e-6 * scale + 1e-6
+    m_ref, c_ref, s_ref = ost.spectrogram_phase(*ost.stft_fft(x))
+    assert float((mag.cpu() - m_ref[:, 0]).abs().max()) < 2e-6 * scale + 1e-6
+    # phase is ill-conditioned where |X| ~ 0: compare re-synthesised real/imag parts instead of cos/sin directly
+    assert float((mag.cpu() * cos.cpu() - m_ref[:, 0] * c_ref[:, 0]).abs().max()) < 4e-6 * scale + 1e-6
+    assert float((mag.cpu() * sin.cpu() - m_ref[:, 0] * s_ref[:, 0]).abs().max()) < 4e-6 * scale + 1e-6
+    strong = m_ref[:, 0] > 1e-2 * scale
+    assert float((cos.cpu() - c_ref[:, 0])[strong].abs().max()) < 2e-4
+    assert float((sin.cpu() - s_ref[:, 0])[strong].abs().max()) < 2e-4
+    # exact silence frames
+    T_sil = (L // 2 - 512) // 160 - 1
+    assert float((mag[2, :T_sil] - 1e-5).abs().max()) < 1e-11
+    assert torch.all(cos[2, :T_sil] == 0) and torch.all(sin[2, :T_sil] == 0)
+
+
+@pytest.mark.parametrize("L", [16000, 160000])
+def test_istft_vs_oracle_and_roundtrip(eng, L):
+    from oracle import stft as ost
+    g = torch.Generator().manual_seed(7)
+    x = (torch.rand(2, L, generator=g) * 2 - 1) * 0.5
+    _, _, _, re, im = eng.stft_magphase(x.to(DEV), want_complex=True)
+    y = eng.istft(re, im, L)
+    assert float((y.cpu() - x).abs().max()) < 5e-6          # STFT -> iSTFT identity
+    # arbitrary (inconsistent) spectrogram vs the oracle
+    T = arch.frames_for(L)
+    sr = torch.randn(2, T, 513, generator=g)
+    si = torch.randn(2, T, 513, generator=g)
+    y = eng.istft(sr.to(DEV), si.to(DEV), L)
+    y_ref = ost.istft_fft(sr[:, None].double(), si[:, None].double(), L)
+    assert float((y.cpu().double() - y_ref).abs().max()) < 1e-5
+
+
+def test_stft_istft_roundtrip_full_batch(eng):
+    """BASELINE config-2 size (B=16, 10 s): size-independent property instead of a CPU comparison."""
+    _, mix = synthetic.make_mixtures(16, 160000)
+    x = torch.from_numpy(mix).to(DEV)
+    _, _, _, re, im = eng.stft_magphase(x, want_complex=True)
+    y = eng.istft(re, im, 160000)
+    assert float((y - x).abs().max()) < 1e-5
+
+
+# ---- FiLM ----------------------------------------------------------------------------------------------------------
+def test_film_vs_oracle_and_golden(eng, oracle_sd, golden_dir):
+    from oracle import resunet as orr
+    cond = torch.from_numpy(synthetic.make_condition(2))
+    raw = eng.film(cond.to(DEV), raw=True).cpu()
+    ref = orr.film_all(oracle_sd, cond)
+    g = np.load(os.path.join(golden_dir, "g1_tiny.npz"))
+    n_checked = 0
+    for site, c, used in arch.film_sites():
+        off = eng.film_offset(site)
+        if not used:
+            assert off == -1
+            continue
+        got = raw[:, off:off + c]
+        np.testing.assert_allclose(got.numpy(), ref[site].numpy(), rtol=0, atol=2e-6)
+        np.testing.assert_allclose(got.numpy(), g["film/" + site], rtol=0, atol=2e-6)
+        n_checked += 1
+    assert n_checked == 32 and eng.film_width() == 9856 - 1600
+
+
+# ---- residual blocks / transposed convs ---------------------------------------------------------------------------
+BLOCKS = [  # (module prefix, film site stem, cin, cout, H, W)
+    ("base.encoder_block1.conv_block1", "encoder_block1->conv_block1", 32, 32, 40, 64),   # identity, PW=32, N=32
+    ("base.encoder_block2.conv_block1", "encoder_block2->conv_block1", 32, 64, 24, 32),   # 1x1 shortcut, N=64
+    ("base.encoder_block5.conv_block1", "encoder_block5->conv_block1", 256, 384, 8, 32),
+    ("base.encoder_block6.conv_block1", "encoder_block6->conv_block1", 384, 384, 12, 16),  # PW=16, ragged H
+    ("base.conv_block7a.conv_block1", "conv_block7a->conv_block1", 384, 384, 4, 8),       # PW=8, H < tile
+    ("base.decoder_block1.conv_block2", "decoder_block1->conv_block2", 768, 384, 4, 16),
+    ("base.decoder_block6.conv_block2", "decoder_block6->conv_block2", 64, 32, 17, 96),   # ragged H, 3 x-tiles
+]
+
+
+@pytest.mark.parametrize("prefix,stem,cin,cout,H,W", BLOCKS)
+def test_convblock_vs_oracle(eng, oracle_sd, prefix, stem, cin, cout, H, W):
+    from oracle import resunet as orr
+    g = torch.Generator().manual_seed(H * 1000 + W)
+    B = 2
+    x = torch.randn(B, cin, H, W, generator=g)
+    cond = torch.from_numpy(synthetic.make_condition(B))
+    shift = eng.film(cond.to(DEV))
+    y = eng.convblock(prefix, x.to(DEV), shift, cout).cpu()
+    ref = orr.conv_block_res(oracle_sd, prefix, x, orr.film(oracle_sd, cond, stem + "->beta1"),
+                             orr.film(oracle_sd, cond, stem + "->beta2"))
+    assert y.shape == ref.shape
+    assert _relerr(y, ref) < 5e-6, _relerr(y, ref)
+    assert float((y - ref).abs().max()) < 1e-4 * max(1.0, float(ref.abs().max()))
+
+
+UPS = [("decoder_block1", 384, 384, (1, 2), 4, 8), ("decoder_block2", 384, 384, (2, 2), 4, 16),
+       ("decoder_block5", 128, 64, (2, 2), 9, 64), ("decoder_block6", 64, 32, (2, 2), 16, 32)]
+
+
+@pytest.mark.parametrize("name,cin,cout,up,h,w", UPS)
+def test_upconv_vs_oracle(eng, oracle_sd, name, cin, cout, up, h, w):
+    import torch.nn.functional as F
+    from oracle import resunet as orr
+    g = torch.Generator().manual_seed(h * 100 + w)
+    B = 2
+    x = torch.randn(B, cin, h, w, generator=g)
+    cond = torch.from_numpy(synthetic.make_condition(B))
+    shift = eng.film(cond.to(DEV))
+    y = eng.upconv("base." + name, x.to(DEV), shift, cout, up).cpu()
+    hh = F.leaky_relu(orr._bn(oracle_sd, f"base.{name}.bn1", x) + orr.film(oracle_sd, cond, f"{name}->beta1"), 0.01)
+    ref = F.conv_transpose2d(hh, oracle_sd[f"base.{name}.conv1.weight"], stride=up)
+    assert y.shape == ref.shape
+    assert _relerr(y, ref) < 2e-6, _relerr(y, ref)
+
+
+# ---- mask ----------------------------------------------------------------------------------------------------------
+def test_mask_apply_vs_oracle(eng, oracle_sd):
+    import torch.nn.functional as F
+    from oracle import stft as ost
+    g = torch.Generator().manual_seed(3)
+    B, T, Tp = 2, 101, 128
+    x12 = torch.randn(B, 32, Tp, 512, generator=g)
+    re = torch.randn(B, 1, T, 513, generator=g)
+    im = torch.randn(B, 1, T, 513, generator=g)
+    mag, cos, sin = ost.spectrogram_phase(re, im)
+    o_re, o_im = eng.mask_apply(x12.to(DEV), mag[:, 0].contiguous().to(DEV), cos[:, 0].contiguous().to(DEV),
+                                sin[:, 0].contiguous().to(DEV))
+    lg = F.conv2d(x12, oracle_sd["base.after_conv.weight"], oracle_sd["base.after_conv.bias"])
+    lg = F.pad(lg, (0, 1))[:, :, 0:T, :]
+    mm = torch.sigmoid(lg[:, 0:1])
+    _, mc, ms = ost.magphase(torch.tanh(lg[:, 1:2]), torch.tanh(lg[:, 2:3]))
+    om = F.relu(mag * mm)
+    ref_re = om * (cos * mc - sin * ms)
+    ref_im = om * (sin * mc + cos * ms)
+    assert float((o_re.cpu() - ref_re[:, 0]).abs().max()) < 5e-6
+    assert float((o_im.cpu() - ref_im[:, 0]).abs().max()) < 5e-6
+    assert torch.all(o_re[:, :, 512] == 0) and torch.all(o_im[:, :, 512] == 0)   # Nyquist bin exactly zero
+
+
+# ---- whole path ------------------------------------------------------------------------------------------------------
+def test_separate_tiny_vs_oracle_and_golden(model, oracle_sd, golden_dir):
+    from oracle import resunet as orr
+    _, mix = synthetic.make_mixtures(2, 16000)
+    cond = synthetic.make_condition(2)
+    inp = {"mixture": torch.from_numpy(mix)[:, None, :].to(DEV), "condition": torch.from_numpy(cond).to(DEV)}
+    out = model(inp)["waveform"]
+    assert out.shape == (2, 1, 16000) and out.dtype == torch.float32 and out.device.type == "cuda"
+    ref = orr.forward(oracle_sd, {"mixture": torch.from_numpy(mix)[:, None, :], "condition": torch.from_numpy(cond)})[
+        "waveform"]
+    err = _rms(out.cpu() - ref)
+    assert err < 2e-6, err                         # north_star bar: 1e-4 RMS
+    g = np.load(os.path.join(golden_dir, "g1_tiny.npz"))
+    assert _rms(out.cpu() - torch.from_numpy(g["waveform"])) < 2e-6   # the reference's own output
+
+
+def test_separate_10s_vs_golden(model, golden_dir):
+    from oracle import metrics as om
+    g = np.load(os.path.join(golden_dir, "g2_clip10s.npz"))
+    src, mix = synthetic.make_mixtures(1, 160000, first=3)
+    cond = synthetic.make_condition(1)
+    out = model({"mixture": torch.from_numpy(mix)[:, None, :].to(DEV), "condition": torch.from_numpy(cond).to(DEV)})[
+        "waveform"][0, 0].cpu().numpy()
+    assert np.sqrt(np.mean((out[::16] - g["waveform_dec"]) ** 2)) < 3e-6
+    np.testing.assert_allclose(out[:2048], g["head"], atol=3e-5)
+    np.testing.assert_allclose(out[-2048:], g["tail"], atol=3e-5)
+    sdr = om.calculate_sdr(src[0], out)
+    sdr0 = om.calculate_sdr(src[0], mix[0])
+    sisdr = om.calculate_sisdr(src[0], out)
+    np.testing.assert_allclose([sdr, sdr - sdr0, sisdr], g["sdr_triple"], atol=0.01)   # bar: +-0.05 dB
+
+
+def test_separate_batch_invariance_full_size(model):
+    """Config-2 size (B=16 x 10 s): clips are independent, so row i of a batched run must equal a batch-1 run of clip i
+    bit for bit; also finite and deterministic across two launches."""
+    _, mix = synthetic.make_mixtures(16, 160000)
+    cond = synthetic.make_condition(16)
+    m = torch.from_numpy(mix)[:, None, :].to(DEV)
+    c = torch.from_numpy(cond).to(DEV)
+    out = model({"mixture": m, "condition": c})["waveform"]
+    out2 = model({"mixture": m, "condition": c})["waveform"]
+    assert torch.isfinite(out).all()
+    assert torch.equal(out, out2)
+    for i in (0, 7, 15):
+        one = model({"mixture": m[i:i + 1], "condition": c[i:i + 1]})["waveform"]
+        assert torch.equal(one[0], out[i]), i
+
+
+def test_silence_and_edge_lengths(model, oracle_sd):
+    from oracle import resunet as orr
+    cond = torch.from_numpy(synthetic.make_condition(1))
+    for L in (1024, 5000, 16001):   # T = 7 / 32 / 101 -> Tpad = 32 / 32 / 128
+        x = torch.zeros(1, 1, L)
+        x[0, 0, L // 3] = 0.5       # a click in silence
+        out = model({"mixture": x.to(DEV), "condition": cond.to(DEV)})["waveform"]
+        ref = orr.forward(oracle_sd, {"mixture": x, "condition": cond})["waveform"]
+        assert out.shape == (1, 1, L)
+        assert _rms(out.cpu() - ref) < 2e-6
+
+
+def test_chunk_inference_vs_golden(model, golden_dir):
+    g = np.load(os.path.join(golden_dir, "g3_chunk.npz"))
+    segs = [synthetic.make_mixtures(1, 160000, first=10 + i)[1][0] for i in range(3)]
+    long_mix = np.concatenate(segs)[:400000].astype(np.float32)
+    cond = synthetic.make_condition(1)
+    out = model.chunk_inference({"mixture": torch.from_numpy(long_mix)[None, None, :].to(DEV),
+                                 "condition": torch.from_numpy(cond).to(DEV)})
+    assert out.shape == (1, 400000) and out.dtype == np.float64
+    assert np.sqrt(np.mean((out[0, ::25] - g["out_dec"]) ** 2)) < 3e-6
+    for s, seam in zip((32000, 128000, 224000, 320000), g["seams"]):
+        np.testing.assert_allclose(out[0, s - 64:s + 64], seam, atol=3e-5)
+    short = model.chunk_inference({"mixture": torch.zeros(1, 1, 160000, device=DEV),
+                                   "condition": torch.from_numpy(cond).to(DEV)})
+    assert short.shape == (1, 160000) and not short.any()
+
+
+# ---- metrics / evaluator ---------------------------------------------------------------------------------------------
+def test_sdr_stats_vs_oracle():
+    from lass_amd import metrics
+    from oracle import metrics as om
+    rng = np.random.default_rng(5)
+    ref = rng.standard_normal(160000).astype(np.float32) * 0.1
+    for est in (ref.copy(), 0.5 * ref, ref + 0.01 * rng.standard_normal(160000).astype(np.float32),
+                np.zeros_like(ref), rng.standard_normal(160000).astype(np.float32)):
+        assert abs(metrics.calculate_sdr(ref, est) - om.calculate_sdr(ref, est)) < 1e-3
+        a, b = metrics.calculate_sisdr(ref, est), om.calculate_sisdr(ref, est)
+        assert abs(a - b) < 1e-2 or (a > 80 and b > 80)   # est == a*ref: both are "infinite", float32 eps-limited
+    assert abs(metrics.calculate_sdr(ref, 0.5 * ref) - 6.0206) < 1e-3
+
+
+def test_evaluator_matches_oracle(tmp_path, model, oracle_sd):
+    """BASELINE config 1 shape (8 synthetic mixtures) at 2 s per clip to keep the CPU oracle fast."""
+    from lass_amd.audiosep import AudioSep, PrecomputedQueryEncoder
+    from lass_amd.evaluator import DCASEEvaluator
+    from oracle import evaluator as oev
+    n, L = 8, 32000
+    csv_path = synthetic.write_validation_set(str(tmp_path), n_clips=n, length=L)
+    qe = PrecomputedQueryEncoder()
+    pl_model = AudioSep(ss_model=model, query_encoder=qe)
+    ev = DCASEEvaluator(sampling_rate=16000, eval_indexes=csv_path, audio_dir=os.path.join(str(tmp_path), "lass_validation"),
+                        batch_size=3)   # ragged last batch on purpose
+    sisdr, sdri, sdr = ev(pl_model)
+    clips = [synthetic.make_clip(i, L) for i in range(n)]
+    conds = qe.get_query_embed("text", [f"synthetic tone cluster {i % 4}" for i in range(n)]).numpy()
+    (o_sisdr, o_sdri, o_sdr), rows = oev.evaluate(oracle_sd, clips, conds)
+    np.testing.assert_allclose(ev.last_rows, rows, atol=0.01)
+    assert abs(sdr - o_sdr) < 0.01 and abs(sdri - o_sdri) < 0.01 and abs(sisdr - o_sisdr) < 0.01
