@@ -25,12 +25,29 @@ PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64
 PEAK_HBM_GBS = 8000.0
 
 
+def host_cores() -> int:
+    """CPU threads this process may actually use: affinity mask, capped by the cgroup CPU quota; a GPU box exposes all
+    of the host's logical CPUs but grants a 16-core share per GPU, and over-subscribing it makes the baseline
+    meaningless."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    env = os.environ.get("LASS_BENCH_CPU_THREADS")
+    if env:
+        return int(env)
+    return min(n, 16)
+
+
 def cpu_baseline(sd, length, seconds_budget=20.0):
     """The oracle (CPU restatement of the reference path) timed on this box's host cores: a bounded sample of the same
     workload (batch-1 forwards of 10 s clips until ~seconds_budget of CPU time is spent)."""
     from lass_amd import synthetic
     from oracle import resunet as orr
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     osd = orr.to_torch(sd)
     _, mix = synthetic.make_mixtures(1, length)
