@@ -6,7 +6,7 @@ import os
 from ctypes import POINTER, c_char_p, c_double, c_int, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "liblass_hip.so")
+LIB_PATH = os.environ.get("LASS_HIP_LIB") or os.path.join(_HERE, "csrc", "liblass_hip.so")  # env: diagnostic builds
 
 _lib = None
 

@@ -9,13 +9,19 @@
 //   p = output pixel   (cols of D  -> the lane, so NCHW stores are 128-B contiguous per half-wave)
 //   k = (input channel, tap)
 // A comes from the re-laid-out weights Wt[cin][tap][cout] (cout contiguous), B from a planar LDS halo tile
-// [cin][row][col]; both fragments are single conflict-free ds_read_b32 per MFMA operand.  The f32 MFMA is a
-// bit-exact f32 FMA chain, so results differ from the reference only by summation order.
+// [cin][row][col]; both fragments are single conflict-free ds_read_b32 per MFMA operand, register-prefetched one
+// k-step ahead.  The f32 MFMA is a bit-exact f32 FMA chain, so results differ from the reference only by summation
+// order.
 //
 // Fusions: BN(eval)+FiLM+leaky-ReLU as a prologue while staging the halo tile (zero padding is applied AFTER the
-// activation, as conv padding does), the block's second activation as conv1's epilogue, residual add / 1x1 shortcut
-// conv (+bias) inside conv2, transposed-conv scatter, channel-slice ("virtual concat") output via batch strides.
+// activation, as conv padding does; the per-channel scale/shift are wave-uniform scalars because a staging pass
+// covers exactly one channel pair), the block's second activation as conv1's epilogue (tables in LDS), the identity
+// residual / shortcut bias as the INITIAL accumulator, the 1x1 shortcut conv as a second K-phase into the same
+// accumulators, transposed-conv scatter, channel-slice ("virtual concat") output via batch strides.
 #include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
 #include "kernels.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -24,18 +30,19 @@ namespace {
 
 constexpr int F_PRO = 1;     // prologue: x*scale[c] + shift[b][c], leaky 0.01
 constexpr int F_PHASEB = 2;  // second K-phase: 1x1 over raw in2 (shortcut conv)
-constexpr int F_BIAS = 4;    // + bias[n]
-constexpr int F_RES = 8;     // + res[b][n][y][x]
+constexpr int F_BIAS = 4;    // + bias[n]            (as initial accumulator)
+constexpr int F_RES = 8;     // + res[b][n][y][x]    (as initial accumulator)
 constexpr int F_EPIACT = 16; // epilogue: leaky(v*scale[n] + shift[b][n])
 constexpr int F_TCONV = 32;  // n = (co, a, bb); scatter to (y*uh+a, x*uw+bb)
 
-constexpr int MAX_CIN = 768;
 constexpr int NTHREADS = 256;
 
-__device__ __forceinline__ float leaky(float v) { return v > 0.f ? v : 0.01f * v; }
+__device__ __forceinline__ float leaky(float v) { return fmaxf(v, 0.01f * v); }  // == v > 0 ? v : 0.01 v
 
-// One K-phase: stages [KC] channels x (rows+halo) x (cols+halo) of input and [KC][TAPS][NT] of weights per chunk,
-// register-prefetching chunk c+1 while chunk c is contracted out of LDS.
+// One K-phase: per chunk, [KC] channels x (rows+halo) x (cols+halo) of input and [KC][TAPS][NT] of weights are staged
+// in LDS; the registers of chunk c+1 are loaded from global memory while chunk c is contracted.
+// Input staging walks the chunk in groups of G channels (G*CH_ELEMS elements, NPASS passes of 256 threads), so the
+// channel of an element is (group, u >= CH_ELEMS): wave-uniform up to one select.
 template <int TAPS, int KC, int NCO, int NPX, int PW, bool PRO>
 struct Phase {
     static constexpr int PH = 32 / PW;
@@ -45,110 +52,200 @@ struct Phase {
     static constexpr int IR = PHT + 2 * HALO;
     static constexpr int IP = PW + 2 * HALO;
     static constexpr int NT = 32 * NCO;
-    static constexpr int IN_ELEMS = KC * IR * IP;
-    static constexpr int NLD = (IN_ELEMS + NTHREADS - 1) / NTHREADS;
+    static constexpr int CH_ELEMS = IR * IP;
+    static constexpr int G = (TAPS == 9) ? 2 : 1;
+    static constexpr int NGRP = KC / G;
+    static constexpr int GRP_ELEMS = G * CH_ELEMS;
+    static constexpr int NPASS = (GRP_ELEMS + NTHREADS - 1) / NTHREADS;
+    static constexpr int IN_ELEMS = KC * CH_ELEMS;
     static constexpr int W_V4 = KC * TAPS * NT / 4;
     static constexpr int NWLD = (W_V4 + NTHREADS - 1) / NTHREADS;
     static constexpr int LDS_FLOATS = IN_ELEMS + KC * TAPS * NT;
     static_assert((IN_ELEMS % 4) == 0, "weight region must stay 16-B aligned");
+    static_assert(KC % G == 0 && G <= 2, "channel grouping");
 
-    int goff[NLD];
-    float v[NLD];
-    float4 wv[NWLD];
+    // Every global load below is UNCONDITIONAL (addresses clamped into the image / the weight slab, the padding zero
+    // applied by a select when the element is written to LDS): a conditional load makes hipcc branch around it and
+    // drain vmcnt at the join, which serialises the prefetch behind a full memory round trip per chunk.
+    int goff[NPASS];        // clamped global offset of this thread's element in pass k of group 0
+    unsigned okbits;        // bit k: the element of pass k lies inside the image (else conv zero padding)
+    float v[NGRP][NPASS];   // prefetched input elements
+    float4 wv[NWLD];        // prefetched weights
+    float psc[KC], psh[KC]; // wave-uniform prologue scale / shift of the prefetched chunk (SGPRs)
+#ifdef LASS_CONV_DIAG
+    long long diag[4] = {0, 0, 0, 0};  // cycles in: compute, barrier-1 wait, store, barrier-2 wait (diagnostic build only)
+#endif
+
+    __device__ __forceinline__ static int upos(int tid, int k) {  // element index within a channel group (clamped:
+        const int u = tid + k * NTHREADS;                        // surplus threads of the last pass duplicate the
+        return u < GRP_ELEMS ? u : GRP_ELEMS - 1;                 // group's last element)
+    }
 
     __device__ __forceinline__ void init(int tid, int y0, int x0, int H, int W) {
+        okbits = 0;
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int e = tid + i * NTHREADS;
-            const int c = e / (IR * IP);
-            const int r = (e / IP) % IR;
-            const int x = e % IP;
+        for (int k = 0; k < NPASS; ++k) {
+            const int u = upos(tid, k);
+            const int cl = (G == 2 && u >= CH_ELEMS) ? 1 : 0;
+            const int w = u - cl * CH_ELEMS;
+            const int r = w / IP, x = w % IP;
             const int gy = y0 + r - HALO, gx = x0 + x - HALO;
-            const bool ok = (e < IN_ELEMS) && gy >= 0 && gy < H && gx >= 0 && gx < W;
-            goff[i] = ok ? (c * H * W + gy * W + gx) : -1;
+            const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const int gyc = min(max(gy, 0), H - 1), gxc = min(max(gx, 0), W - 1);
+            goff[k] = cl * H * W + gyc * W + gxc;
+            okbits |= (ok ? 1u : 0u) << k;
         }
     }
 
-    // in_c0: pointer to channel c0 of this clip; w_c0: pointer to Wt[c0][0][n0]
-    __device__ __forceinline__ void load(const float* __restrict__ in_c0, const float* __restrict__ w_c0, int Nw,
-                                         int tid) {
+    // in_c0: channel c0 of this clip; w_c0: Wt[c0][0][n0]; sc/sh: prologue tables at channel c0 (PRO only)
+    __device__ __forceinline__ void load(const float* __restrict__ in_c0, int HW, const float* __restrict__ w_c0,
+                                         int Nw, const float* __restrict__ sc, const float* __restrict__ sh, int tid) {
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) v[i] = goff[i] >= 0 ? in_c0[goff[i]] : 0.f;
+        for (int q = 0; q < NGRP; ++q)
+#pragma unroll
+            for (int k = 0; k < NPASS; ++k) v[q][k] = in_c0[(size_t)q * G * HW + goff[k]];
 #pragma unroll
         for (int i = 0; i < NWLD; ++i) {
-            const int e = tid + i * NTHREADS;  // float4 index into [KC*TAPS][NT/4]
-            if (e < W_V4) {
-                const int row = e / (NT / 4), col = e % (NT / 4);
-                wv[i] = *reinterpret_cast<const float4*>(w_c0 + (size_t)row * Nw + col * 4);
+            const int e0 = tid + i * NTHREADS;  // float4 index into [KC*TAPS][NT/4]
+            const int e = e0 < W_V4 ? e0 : W_V4 - 1;
+            const int row = e / (NT / 4), col = e % (NT / 4);
+            wv[i] = *reinterpret_cast<const float4*>(w_c0 + (size_t)row * Nw + col * 4);
+        }
+        if (PRO) {
+#pragma unroll
+            for (int c = 0; c < KC; ++c) {
+                psc[c] = sc[c];
+                psh[c] = sh[c];
             }
         }
     }
 
-    __device__ __forceinline__ void store(float* lds, const float* lds_sc, const float* lds_sh, int c0, int tid) {
+    __device__ __forceinline__ void store(float* lds, int tid) {
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int e = tid + i * NTHREADS;
-            if (e < IN_ELEMS) {
-                float t = v[i];
+        for (int q = 0; q < NGRP; ++q)
+#pragma unroll
+            for (int k = 0; k < NPASS; ++k) {
+                const int u = upos(tid, k);
+                float t = v[q][k];
                 if (PRO) {
-                    const int c = c0 + e / (IR * IP);
-                    t = goff[i] >= 0 ? leaky(t * lds_sc[c] + lds_sh[c]) : 0.f;
+                    const bool hi = (G == 2) && (u >= CH_ELEMS);
+                    const float s = hi ? psc[q * G + G - 1] : psc[q * G];
+                    const float h = hi ? psh[q * G + G - 1] : psh[q * G];
+                    t = leaky(t * s + h);
                 }
-                lds[e] = t;
+                t = ((okbits >> k) & 1u) ? t : 0.f;  // conv zero padding comes after the activation
+                lds[q * GRP_ELEMS + u] = t;
             }
-        }
         float4* lw = reinterpret_cast<float4*>(lds + IN_ELEMS);
 #pragma unroll
         for (int i = 0; i < NWLD; ++i) {
-            const int e = tid + i * NTHREADS;
-            if (e < W_V4) lw[e] = wv[i];
+            const int e0 = tid + i * NTHREADS;
+            lw[e0 < W_V4 ? e0 : W_V4 - 1] = wv[i];
         }
     }
 
     __device__ __forceinline__ static void compute(const float* lds, f32x16 (&acc)[NCO][NPX], int lane, int wave) {
         const int khalf = lane >> 5, j = lane & 31;
         const int ty = j / PW, tx = j % PW;
-        const float* bbase = lds + khalf * (IR * IP) + (wave * WROWS + ty) * IP + tx;
+        const float* bbase = lds + khalf * CH_ELEMS + (wave * WROWS + ty) * IP + tx;
         const float* abase = lds + IN_ELEMS + khalf * (TAPS * NT) + j;
+        constexpr int S = (KC / 2) * TAPS;  // k-steps: (channel pair, tap)
+        // register double-buffered fragments: the reads of step s+1 are issued before the MFMAs of step s
+        float a[2][NCO], b[2][NPX];
+        auto rd = [&](int s, float (&aa)[NCO], float (&bb)[NPX]) {
+            const int kk = s / TAPS, tap = s % TAPS;
 #pragma unroll
-        for (int kk = 0; kk < KC / 2; ++kk) {
+            for (int co = 0; co < NCO; ++co) aa[co] = abase[(kk * 2 * TAPS + tap) * NT + co * 32];
 #pragma unroll
-            for (int tap = 0; tap < TAPS; ++tap) {
-                float a[NCO], b[NPX];
+            for (int px = 0; px < NPX; ++px)
+                bb[px] = bbase[kk * 2 * CH_ELEMS + (px * PH + (TAPS == 9 ? tap / 3 : 0)) * IP +
+                               (TAPS == 9 ? tap % 3 : 0)];
+        };
+        rd(0, a[0], b[0]);
 #pragma unroll
-                for (int co = 0; co < NCO; ++co) a[co] = abase[(kk * 2 * TAPS + tap) * NT + co * 32];
+        for (int s = 0; s < S; ++s) {
+            if (s + 1 < S) rd(s + 1, a[(s + 1) & 1], b[(s + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ABOVE this step's MFMAs (hipcc sinks it otherwise)
+#pragma unroll
+            for (int co = 0; co < NCO; ++co)
 #pragma unroll
                 for (int px = 0; px < NPX; ++px)
-                    b[px] = bbase[kk * 2 * (IR * IP) + (px * PH + (TAPS == 9 ? tap / 3 : 0)) * IP +
-                                  (TAPS == 9 ? tap % 3 : 0)];
-#pragma unroll
-                for (int co = 0; co < NCO; ++co)
-#pragma unroll
-                    for (int px = 0; px < NPX; ++px)
-                        acc[co][px] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[co], b[px], acc[co][px], 0, 0, 0);
-            }
+                    acc[co][px] =
+                        __builtin_amdgcn_mfma_f32_32x32x2f32(a[s & 1][co], b[s & 1][px], acc[co][px], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
-    // Run the whole phase.  `in_b`: clip base of the input tensor; Wt: [Cin][TAPS][Nw] (+n0 applied here).
-    __device__ __forceinline__ void run(float* lds, const float* lds_sc, const float* lds_sh,
-                                        const float* __restrict__ in_b, int Cin, int HW,
-                                        const float* __restrict__ Wt, int Nw, int n0, f32x16 (&acc)[NCO][NPX],
-                                        int tid, int y0, int x0, int H, int W) {
+    // Single-buffered LDS, two barriers per chunk.
+    __device__ __forceinline__ void run(float* lds, const float* __restrict__ in_b, int Cin, int HW,
+                                        const float* __restrict__ Wt, int Nw, int n0,
+                                        const float* __restrict__ sc, const float* __restrict__ sh,
+                                        f32x16 (&acc)[NCO][NPX], int tid, int y0, int x0, int H, int W) {
         const int lane = tid & 63, wave = tid >> 6;
         init(tid, y0, x0, H, W);
         const int nchunks = Cin / KC;
-        load(in_b, Wt + n0, Nw, tid);
-        __syncthreads();  // previous phase's LDS reads (and the prologue tables) are complete
-        store(lds, lds_sc, lds_sh, 0, tid);
+        load(in_b, HW, Wt + n0, Nw, sc, sh, tid);
+        __syncthreads();  // previous phase's LDS reads (and the epilogue tables) are complete
+        store(lds, tid);
         __syncthreads();
         for (int ch = 0; ch < nchunks; ++ch) {
             const bool more = ch + 1 < nchunks;
+#ifdef LASS_CONV_DIAG
+            const long long t0 = clock64();
+#endif
             if (more)
-                load(in_b + (size_t)(ch + 1) * KC * HW, Wt + (size_t)(ch + 1) * KC * TAPS * Nw + n0, Nw, tid);
+                load(in_b + (size_t)(ch + 1) * KC * HW, HW, Wt + (size_t)(ch + 1) * KC * TAPS * Nw + n0, Nw,
+                     sc + (ch + 1) * KC, sh + (ch + 1) * KC, tid);
             compute(lds, acc, lane, wave);
+#ifdef LASS_CONV_DIAG
+            const long long t1 = clock64();
+#endif
             __syncthreads();
-            if (more) store(lds, lds_sc, lds_sh, (ch + 1) * KC, tid);
+#ifdef LASS_CONV_DIAG
+            const long long t2 = clock64();
+#endif
+            if (more) store(lds, tid);
+#ifdef LASS_CONV_DIAG
+            const long long t3 = clock64();
+#endif
+            __syncthreads();
+#ifdef LASS_CONV_DIAG
+            diag[0] += t1 - t0; diag[1] += t2 - t1; diag[2] += t3 - t2; diag[3] += clock64() - t3;
+#endif
+        }
+    }
+
+    // Double-buffered variant: chunk c+1 is written into the other LDS buffer at the top of iteration c (its registers
+    // were loaded one iteration earlier), chunk c+2's global loads are issued, then chunk c is contracted: ONE barrier
+    // per chunk.  The chunk loop is unrolled by two so both buffer addresses are compile-time constants.
+    __device__ __forceinline__ void run_db(float* lds, int buf_stride, const float* __restrict__ in_b, int Cin, int HW,
+                                           const float* __restrict__ Wt, int Nw, int n0,
+                                           const float* __restrict__ sc, const float* __restrict__ sh,
+                                           f32x16 (&acc)[NCO][NPX], int tid, int y0, int x0, int H, int W) {
+        const int lane = tid & 63, wave = tid >> 6;
+        float* buf0 = lds;
+        float* buf1 = lds + buf_stride;
+        init(tid, y0, x0, H, W);
+        const int nchunks = Cin / KC;  // even (host-checked)
+        auto ld = [&](int c) {
+            load(in_b + (size_t)c * KC * HW, HW, Wt + (size_t)c * KC * TAPS * Nw + n0, Nw, sc + c * KC, sh + c * KC,
+                 tid);
+        };
+        ld(0);
+        __syncthreads();  // previous phase's LDS reads complete; epilogue tables visible
+        store(buf0, tid);
+        ld(1);
+        __syncthreads();
+        for (int ch = 0; ch < nchunks; ch += 2) {
+            store(buf1, tid);  // chunk ch+1 (always exists)
+            if (ch + 2 < nchunks) ld(ch + 2);
+            compute(buf0, acc, lane, wave);
+            __syncthreads();
+            if (ch + 2 < nchunks) {
+                store(buf0, tid);  // chunk ch+2
+                if (ch + 3 < nchunks) ld(ch + 3);
+            }
+            compute(buf1, acc, lane, wave);
             __syncthreads();
         }
     }
@@ -159,56 +256,90 @@ struct MaxI {
     static constexpr int v = A > B ? A : B;
 };
 
-template <int TAPS, int NCO, int NPX, int PW, int FLAGS>
+template <int TAPS, int NCO, int NPX, int PW, int FLAGS, int VAR>
 __global__ __launch_bounds__(NTHREADS) void conv_kernel(ConvArgs p) {
     constexpr bool PRO = (FLAGS & F_PRO) != 0;
+    constexpr bool DB = (VAR & 1) != 0;  // double-buffered LDS, one barrier per chunk
     constexpr int KCA = (TAPS == 9) ? 8 : 16;
     using PA = Phase<TAPS, KCA, NCO, NPX, PW, PRO>;
     using PB = Phase<1, 16, NCO, NPX, PW, false>;
-    constexpr int LDS_MAIN = (FLAGS & F_PHASEB) ? MaxI<PA::LDS_FLOATS, PB::LDS_FLOATS>::v : PA::LDS_FLOATS;
+    constexpr int LDS_ONE = (FLAGS & F_PHASEB) ? MaxI<PA::LDS_FLOATS, PB::LDS_FLOATS>::v : PA::LDS_FLOATS;
+    constexpr int LDS_MAIN = DB ? 2 * LDS_ONE : LDS_ONE;
     constexpr int PH = PA::PH, WROWS = PA::WROWS, PHT = PA::PHT, NT = PA::NT;
+    constexpr bool EPI = (FLAGS & F_EPIACT) != 0;
 
-    __shared__ __attribute__((aligned(16))) float lds[LDS_MAIN + (PRO ? 2 * MAX_CIN : 0)];
-    float* lds_sc = lds + LDS_MAIN;
-    float* lds_sh = lds_sc + MAX_CIN;
+    __shared__ __attribute__((aligned(16))) float lds[LDS_MAIN + (EPI ? 2 * NT : 0)];
+    float* lds_es = lds + LDS_MAIN;  // epilogue scale / shift for this block's NT output channels
+    float* lds_eh = lds_es + NT;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.z;
     const int n0 = blockIdx.y * NT;
+#ifdef LASS_CONV_DIAG
+    const long long k_c0 = clock64(), k_r0 = wall_clock64();
+    long long dsum[4] = {0, 0, 0, 0};
+#endif
     const int tiles_x = p.W / PW;
     const int y0 = (blockIdx.x / tiles_x) * PHT;
     const int x0 = (blockIdx.x % tiles_x) * PW;
     const int HW = p.H * p.W;
+    const int khalf = lane >> 5, j = lane & 31;
+    const int ty = j / PW, tx = j % PW;
+    const int x = x0 + tx;
 
+    if (EPI) {
+        if (tid < NT) {
+            lds_es[tid] = p.epi_scale[n0 + tid];
+            lds_eh[tid] = p.epi_shift[(size_t)b * p.epi_shift_bs + n0 + tid];
+        }
+    }
+
+    // ---- accumulator initialisation: 0, the shortcut bias, or the identity residual ---------------------------
     f32x16 acc[NCO][NPX];
 #pragma unroll
     for (int co = 0; co < NCO; ++co)
 #pragma unroll
-        for (int px = 0; px < NPX; ++px)
+        for (int px = 0; px < NPX; ++px) {
+            const int y = y0 + wave * WROWS + px * PH + ty;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[co][px][r] = 0.f;
-
-    if (PRO) {
-        for (int c = tid; c < p.Cin; c += NTHREADS) {
-            lds_sc[c] = p.pro_scale[c];
-            lds_sh[c] = p.pro_shift[(size_t)b * p.pro_shift_bs + c];
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + co * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                float v = 0.f;
+                if (FLAGS & F_BIAS) v = p.bias[n];
+                if (FLAGS & F_RES)  // unconditional (row clamped; rows >= H are never stored)
+                    v = p.res[(size_t)b * p.res_bs + (size_t)n * HW + (size_t)min(y, p.H - 1) * p.W + x];
+                acc[co][px][r] = v;
+            }
         }
-    }
+
+    const float* sc = PRO ? p.pro_scale : nullptr;
+    const float* sh = PRO ? p.pro_shift + (size_t)b * p.pro_shift_bs : nullptr;
     {
         PA ph;
-        ph.run(lds, lds_sc, lds_sh, p.in + (size_t)b * p.in_bs, p.Cin, HW, p.w, p.Nw, n0, acc, tid, y0, x0, p.H, p.W);
+        if (DB)
+            ph.run_db(lds, LDS_ONE, p.in + (size_t)b * p.in_bs, p.Cin, HW, p.w, p.Nw, n0, sc, sh, acc, tid, y0, x0, p.H,
+                      p.W);
+        else
+            ph.run(lds, p.in + (size_t)b * p.in_bs, p.Cin, HW, p.w, p.Nw, n0, sc, sh, acc, tid, y0, x0, p.H, p.W);
+#ifdef LASS_CONV_DIAG
+        for (int i = 0; i < 4; ++i) dsum[i] += ph.diag[i];
+#endif
     }
+#ifdef LASS_CONV_DIAG
+    const long long k_c1 = clock64();
+#endif
     if (FLAGS & F_PHASEB) {
         PB ph;
-        ph.run(lds, nullptr, nullptr, p.in2 + (size_t)b * p.in2_bs, p.Cin2, HW, p.w2, p.Nw, n0, acc, tid, y0, x0,
-               p.H, p.W);
+        if (DB)
+            ph.run_db(lds, LDS_ONE, p.in2 + (size_t)b * p.in2_bs, p.Cin2, HW, p.w2, p.Nw, n0, nullptr, nullptr, acc,
+                      tid, y0, x0, p.H, p.W);
+        else
+            ph.run(lds, p.in2 + (size_t)b * p.in2_bs, p.Cin2, HW, p.w2, p.Nw, n0, nullptr, nullptr, acc, tid, y0, x0,
+                   p.H, p.W);
     }
 
-    // ---- epilogue: D row (register) = output channel, D col (lane&31) = pixel -----------------------------------
-    const int khalf = lane >> 5, j = lane & 31;
-    const int ty = j / PW, tx = j % PW;
-    const int x = x0 + tx;
+    // ---- epilogue: D row (register) = output channel, D col (lane&31) = pixel; stores only --------------------
 #pragma unroll
     for (int co = 0; co < NCO; ++co) {
 #pragma unroll
@@ -229,26 +360,90 @@ __global__ __launch_bounds__(NTHREADS) void conv_kernel(ConvArgs p) {
                     *reinterpret_cast<float2*>(dst) = o;
                 }
             } else {
+                float* dst =
+                    p.out + (size_t)b * p.out_bs + (size_t)(n0 + co * 32 + 4 * khalf) * HW + (size_t)y * p.W + x;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int n = n0 + co * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                    const int nl = (r & 3) + 8 * (r >> 2);  // + co*32 + 4*khalf
                     float v = acc[co][px][r];
-                    const size_t pix = (size_t)n * HW + (size_t)y * p.W + x;
-                    if (FLAGS & F_BIAS) v += p.bias[n];
-                    if (FLAGS & F_RES) v += p.res[(size_t)b * p.res_bs + pix];
-                    if (FLAGS & F_EPIACT) v = leaky(v * p.epi_scale[n] + p.epi_shift[(size_t)b * p.epi_shift_bs + n]);
-                    p.out[(size_t)b * p.out_bs + pix] = v;
+                    if (EPI) v = leaky(v * lds_es[co * 32 + 4 * khalf + nl] + lds_eh[co * 32 + 4 * khalf + nl]);
+                    dst[(size_t)nl * HW] = v;
                 }
             }
         }
     }
+#ifdef LASS_CONV_DIAG
+    if (p.dbg && tid == 0) {
+        const long long k_c2 = clock64(), k_r2 = wall_clock64();
+        long long* d = p.dbg + 8 * ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+        d[0] = dsum[0]; d[1] = dsum[1]; d[2] = dsum[2]; d[3] = dsum[3];
+        d[4] = k_c1 - k_c0;   // start .. end of main K phase
+        d[5] = k_c2 - k_c0;   // whole block, shader cycles
+        d[6] = k_r2 - k_r0;   // whole block, 100 MHz ticks
+        d[7] = k_r0;
+    }
+#endif
 }
 
+// -1 = automatic (double-buffered LDS for the 64-wide 3x3 tiles, where it measured 1-9 % faster; single-buffered for
+// the 32-wide tiles and the 1-tap kernels, which prefer the higher occupancy); 0 / 1 force a variant (A/B runs).
+int conv_variant() {
+    static int v = [] {
+        const char* e = getenv("LASS_CONV_VARIANT");
+        return e ? atoi(e) : -1;
+    }();
+    return v;
+}
+
+#ifdef LASS_CONV_DIAG
+void diag_report(long long* dbuf, size_t nblk, const ConvArgs& p, int taps) {
+    std::vector<long long> h(nblk * 8);
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpy(h.data(), dbuf, nblk * 64, hipMemcpyDeviceToHost);
+    double s[7] = {0};
+    long long rmin = h[7], rmax = 0;
+    for (size_t i = 0; i < nblk; ++i) {
+        for (int k = 0; k < 7; ++k) s[k] += (double)h[i * 8 + k];
+        if (h[i * 8 + 7] < rmin) rmin = h[i * 8 + 7];
+        if (h[i * 8 + 7] + h[i * 8 + 6] > rmax) rmax = h[i * 8 + 7] + h[i * 8 + 6];
+    }
+    for (double& v : s) v /= (double)nblk;
+    const double clk_ghz = s[5] / s[6] * 0.1;
+    fprintf(stderr,
+            "[diag] taps=%d Cin=%d N=%d %dx%d blocks=%zu | per-block cycles: compute %.0f  bar1 %.0f  store %.0f  bar2 "
+            "%.0f | Kphase %.0f total %.0f | clock %.3f GHz | kernel span %.3f ms\n",
+            taps, p.Cin, p.N, p.H, p.W, nblk, s[0], s[1], s[2], s[3], s[4], s[5], clk_ghz, (rmax - rmin) * 1e-5);
+}
+#endif
+
 template <int TAPS, int NCO, int NPX, int PW, int FLAGS>
-hipError_t launch_one(const ConvArgs& p, hipStream_t stream) {
+hipError_t launch_one(const ConvArgs& p0, hipStream_t stream) {
     constexpr int PHT = 4 * NPX * (32 / PW);
+    ConvArgs p = p0;
     dim3 grid((p.W / PW) * ((p.H + PHT - 1) / PHT), p.N / (32 * NCO), p.B);
-    hipLaunchKernelGGL((conv_kernel<TAPS, NCO, NPX, PW, FLAGS>), grid, dim3(NTHREADS), 0, stream, p);
+#ifdef LASS_CONV_DIAG
+    static long long* dbuf = nullptr;
+    static size_t dcap = 0;
+    const size_t nblk = (size_t)grid.x * grid.y * grid.z;
+    if (nblk > dcap) {
+        if (dbuf) (void)hipFree(dbuf);
+        (void)hipMalloc((void**)&dbuf, nblk * 64);
+        dcap = nblk;
+    }
+    p.dbg = dbuf;
+    struct Rep {
+        long long* d;
+        size_t n;
+        const ConvArgs& p;
+        ~Rep() { diag_report(d, n, p, TAPS); }
+    } rep{dbuf, nblk, p};
+#endif
+    const int var = conv_variant();
+    const bool db = var < 0 ? (TAPS == 9 && NCO == 2 && PW == 32) : (var & 1) != 0;
+    if (db)
+        hipLaunchKernelGGL((conv_kernel<TAPS, NCO, NPX, PW, FLAGS, 1>), grid, dim3(NTHREADS), 0, stream, p);
+    else
+        hipLaunchKernelGGL((conv_kernel<TAPS, NCO, NPX, PW, FLAGS, 0>), grid, dim3(NTHREADS), 0, stream, p);
     return hipGetLastError();
 }
 
@@ -273,8 +468,8 @@ static bool conv_args_ok(const ConvArgs& p, int taps, bool phaseb) {
     if (p.W != 8 && p.W != 16 && (p.W % 32) != 0) return false;
     if (p.N % 32 != 0 || p.Nw < p.N || (p.Nw % 4) != 0) return false;
     const int kc = taps == 9 ? 8 : 16;
-    if (p.Cin <= 0 || p.Cin % kc != 0 || p.Cin > MAX_CIN) return false;
-    if (phaseb && (p.Cin2 <= 0 || p.Cin2 % 16 != 0)) return false;
+    if (p.Cin <= 0 || p.Cin % (2 * kc) != 0) return false;  // even chunk count (run_db)
+    if (phaseb && (p.Cin2 <= 0 || p.Cin2 % 32 != 0)) return false;
     if (!p.in || !p.w || !p.out) return false;
     return true;
 }

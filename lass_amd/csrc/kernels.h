@@ -37,6 +37,7 @@ struct ConvArgs {
     int B = 0, H = 0, W = 0;
     int N = 0;  // output channels computed by this launch (GEMM rows)
     int up_h = 1;  // TCONV: vertical stride (1 or 2); horizontal stride is always 2
+    long long* dbg = nullptr;  // diagnostic builds (-DLASS_CONV_DIAG) only: 8 int64 per block
 };
 
 enum ConvKind { CONV1_ACT = 0, CONV2_IDENT = 1, CONV2_SHORTCUT = 2, TCONV_ACT = 3 };
