@@ -7,6 +7,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -77,6 +78,7 @@ struct lass_ctx {
     int dec_site[6] = {0};           // decoder_blockN->beta1
     std::vector<void*> owned;        // derived device buffers to free
     // profiling
+    bool fuse_pool = true;  // LASS_FUSE_POOL=0 selects the stand-alone pool kernel (A/B + parity of both paths)
     bool profiling = false;
     std::vector<ProfEntry> prof;
     std::vector<hipEvent_t> ev_pool;
@@ -279,8 +281,9 @@ void prof_collect(lass_ctx* c) {
 
 // ---- one residual block ---------------------------------------------------------------------------------------------
 // x: (B,cin,H,W) batch stride x_bs; out: batch stride out_bs (may be a channel slice of a concat buffer).
+// pool_out (optional): the block's avg-pooled output (B,cout,H/pool_h,W/2), produced by conv2's epilogue.
 int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int B, int H, int W, const float* shift,
-                 float* a2, float* out, long out_bs, hipStream_t st) {
+                 float* a2, float* out, long out_bs, hipStream_t st, float* pool_out = nullptr, int pool_h = 2) {
     const Site& s1 = c->sites[rb.s1];
     const Site& s2 = c->sites[rb.s2];
     const long HW = (long)H * W;
@@ -296,6 +299,7 @@ int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int
     ConvArgs q;
     q.in = a2; q.in_bs = rb.cout * HW; q.Cin = rb.cout; q.w = rb.w2; q.Nw = rb.cout; q.N = rb.cout;
     q.out = out; q.out_bs = out_bs; q.B = B; q.H = H; q.W = W;
+    q.pool_out = pool_out; q.pool_h = pool_h;
     ProfScope ps(c, st, P_CONV3X3);
     if (rb.cin == rb.cout) {
         q.res = x; q.res_bs = x_bs;
@@ -416,6 +420,7 @@ int lass_create(lass_ctx** out, int device_id) {
     }
     lass_ctx* c = new lass_ctx();
     c->device = device_id;
+    if (const char* e = getenv("LASS_FUSE_POOL")) c->fuse_pool = atoi(e) != 0;
     c->prof.resize(P_COUNT);
     for (int i = 0; i < P_COUNT; ++i) c->prof[i].name = kProfNames[i];
     build_arch(c);
@@ -685,11 +690,16 @@ int lass_separate(lass_ctx* c, const float* mixture, const float* condition, flo
             o = F(pl.center);
             o_bs = rb.cout * HW;
         }
-        r = run_resblock(c, rb, x, rb.cin * HW, B, H, W, shift, F(pl.a2), o, o_bs, st);
+        // F.avg_pool2d (resunet.py:197) is fused into conv2's epilogue; W >= 16 at every pooled level
+        const bool fuse_pool = i < 6 && c->fuse_pool && (H % kEnc[i].dh) == 0;
+        r = run_resblock(c, rb, x, rb.cin * HW, B, H, W, shift, F(pl.a2), o, o_bs, st,
+                         fuse_pool ? F(pl.pool[i]) : nullptr, kEnc[i].dh);
         if (r) return r;
         if (i < 6) {
-            ProfScope ps(c, st, P_POOL);
-            HIP_TRY(c, lass_launch_pool(o, o_bs, B, rb.cout, H, W, kEnc[i].dh, kEnc[i].dw, F(pl.pool[i]), st));
+            if (!fuse_pool) {
+                ProfScope ps(c, st, P_POOL);
+                HIP_TRY(c, lass_launch_pool(o, o_bs, B, rb.cout, H, W, kEnc[i].dh, kEnc[i].dw, F(pl.pool[i]), st));
+            }
             x = F(pl.pool[i]);
         } else {
             x = o;  // downsample (1,1) is the identity (resunet.py:363-370)

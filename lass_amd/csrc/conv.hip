@@ -72,9 +72,6 @@ struct Phase {
     float v[NGRP][NPASS];   // prefetched input elements
     float4 wv[NWLD];        // prefetched weights
     float psc[KC], psh[KC]; // wave-uniform prologue scale / shift of the prefetched chunk (SGPRs)
-#ifdef LASS_CONV_DIAG
-    long long diag[4] = {0, 0, 0, 0};  // cycles in: compute, barrier-1 wait, store, barrier-2 wait (diagnostic build only)
-#endif
 
     __device__ __forceinline__ static int upos(int tid, int k) {  // element index within a channel group (clamped:
         const int u = tid + k * NTHREADS;                        // surplus threads of the last pass duplicate the
@@ -176,45 +173,6 @@ struct Phase {
         }
     }
 
-    // Single-buffered LDS, two barriers per chunk.
-    __device__ __forceinline__ void run(float* lds, const float* __restrict__ in_b, int Cin, int HW,
-                                        const float* __restrict__ Wt, int Nw, int n0,
-                                        const float* __restrict__ sc, const float* __restrict__ sh,
-                                        f32x16 (&acc)[NCO][NPX], int tid, int y0, int x0, int H, int W) {
-        const int lane = tid & 63, wave = tid >> 6;
-        init(tid, y0, x0, H, W);
-        const int nchunks = Cin / KC;
-        load(in_b, HW, Wt + n0, Nw, sc, sh, tid);
-        __syncthreads();  // previous phase's LDS reads (and the epilogue tables) are complete
-        store(lds, tid);
-        __syncthreads();
-        for (int ch = 0; ch < nchunks; ++ch) {
-            const bool more = ch + 1 < nchunks;
-#ifdef LASS_CONV_DIAG
-            const long long t0 = clock64();
-#endif
-            if (more)
-                load(in_b + (size_t)(ch + 1) * KC * HW, HW, Wt + (size_t)(ch + 1) * KC * TAPS * Nw + n0, Nw,
-                     sc + (ch + 1) * KC, sh + (ch + 1) * KC, tid);
-            compute(lds, acc, lane, wave);
-#ifdef LASS_CONV_DIAG
-            const long long t1 = clock64();
-#endif
-            __syncthreads();
-#ifdef LASS_CONV_DIAG
-            const long long t2 = clock64();
-#endif
-            if (more) store(lds, tid);
-#ifdef LASS_CONV_DIAG
-            const long long t3 = clock64();
-#endif
-            __syncthreads();
-#ifdef LASS_CONV_DIAG
-            diag[0] += t1 - t0; diag[1] += t2 - t1; diag[2] += t3 - t2; diag[3] += clock64() - t3;
-#endif
-        }
-    }
-
     // Double-buffered variant: chunk c+1 is written into the other LDS buffer at the top of iteration c (its registers
     // were loaded one iteration earlier), chunk c+2's global loads are issued, then chunk c is contracted: ONE barrier
     // per chunk.  The chunk loop is unrolled by two so both buffer addresses are compile-time constants.
@@ -256,15 +214,122 @@ struct MaxI {
     static constexpr int v = A > B ? A : B;
 };
 
-template <int TAPS, int NCO, int NPX, int PW, int FLAGS, int VAR>
-__global__ __launch_bounds__(NTHREADS) void conv_kernel(ConvArgs p) {
+
+// Transposed-conv scatter: n = co_real*(uh*2) + a*2 + bb; registers (r, r+1), r even, are bb = 0/1 of one (co_real, a),
+// so each lane writes 8 contiguous bytes and a half-wave a contiguous 256-B run of the up-sampled row.
+template <int NCO, int NPX, int PW>
+__device__ __forceinline__ void tconv_store(const ConvArgs& p, f32x16 (&acc)[NCO][NPX], int b, int n0, int y0, int x0,
+                                            int lane, int wave) {
+    constexpr int PH = 32 / PW, WROWS = NPX * PH;
+    const int HW = p.H * p.W;
+    const int khalf = lane >> 5, j = lane & 31;
+    const int ty = j / PW, tx = j % PW;
+    const int x = x0 + tx;
+    const int uhw = p.up_h * 2;
+    const size_t oHW = (size_t)HW * uhw;
+    const int oW = p.W * 2;
+#pragma unroll
+    for (int co = 0; co < NCO; ++co)
+#pragma unroll
+        for (int px = 0; px < NPX; ++px) {
+            const int y = y0 + wave * WROWS + px * PH + ty;
+            if (y >= p.H) continue;
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const int n = n0 + co * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                const int co_real = n / uhw, a = (n % uhw) >> 1;
+                float2 o = make_float2(acc[co][px][r], acc[co][px][r + 1]);
+                float* dst = p.out + (size_t)b * p.out_bs + co_real * oHW + (size_t)(y * p.up_h + a) * oW + x * 2;
+                *reinterpret_cast<float2*>(dst) = o;
+            }
+        }
+}
+
+// Final store of one wave's accumulators (non-transposed kernels): optional prefetched residual, optional epilogue
+// activation, and optionally the block's F.avg_pool2d (resunet.py:197) fused in: the 2x2 (or 1x2) window of a pooled
+// pixel is (px-tile 0, px-tile 1) x (lane, lane^1), summed in the reference's row-major order.
+template <int NCO, int NPX, int PW, int FLAGS, bool HAVE_RTMP>
+__device__ __forceinline__ void store_tile(const ConvArgs& p, f32x16 (&acc)[NCO][NPX], const float (*rtmp)[16],
+                                           const float* lds_es, const float* lds_eh, int b, int n0, int y0, int x0,
+                                           int lane, int wave) {
+    constexpr int PH = 32 / PW, WROWS = NPX * PH;
+    constexpr bool EPI = (FLAGS & F_EPIACT) != 0;
+    constexpr bool RES = (FLAGS & F_RES) != 0;
+    const int HW = p.H * p.W;
+    const int khalf = lane >> 5, j = lane & 31;
+    const int ty = j / PW, tx = j % PW;
+    const int x = x0 + tx;
+#pragma unroll
+    for (int co = 0; co < NCO; ++co) {
+        float val[NPX][16];
+#pragma unroll
+        for (int px = 0; px < NPX; ++px) {
+            const int y = y0 + wave * WROWS + px * PH + ty;
+            const size_t pix = (size_t)(n0 + co * 32 + 4 * khalf) * HW + (size_t)min(y, p.H - 1) * p.W + x;
+            float radd[16];
+            if (RES && !HAVE_RTMP) {  // batch of 16 unconditional loads, then one wait
+                const float* src = p.res + (size_t)b * p.res_bs + pix;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) radd[r] = src[(size_t)((r & 3) + 8 * (r >> 2)) * HW];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int nl = (r & 3) + 8 * (r >> 2);  // + co*32 + 4*khalf
+                float v = acc[co][px][r];
+                if (RES && HAVE_RTMP) v += rtmp[px][r];
+                if (RES && !HAVE_RTMP) v += radd[r];
+                if (EPI) v = leaky(v * lds_es[co * 32 + 4 * khalf + nl] + lds_eh[co * 32 + 4 * khalf + nl]);
+                val[px][r] = v;
+            }
+            if (y < p.H) {
+                float* dst = p.out + (size_t)b * p.out_bs + pix;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dst[(size_t)((r & 3) + 8 * (r >> 2)) * HW] = val[px][r];
+            }
+        }
+        if (p.pool_out) {  // wave-uniform
+            const int Wo = p.W / 2;
+            if (p.pool_h == 2) {
+                if (PW == 32 && NPX == 2) {
+                    const int y = y0 + wave * WROWS;  // even row of the pair (px-tile 0); px-tile 1 is y+1
+                    const int Ho = p.H / 2;
+                    float* dst = p.pool_out + ((size_t)b * p.N + n0 + co * 32 + 4 * khalf) * Ho * Wo +
+                                 (size_t)(y >> 1) * Wo + (x >> 1);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float o0 = __shfl_xor(val[0][r], 1, 64), o1 = __shfl_xor(val[NPX - 1][r], 1, 64);
+                        float sum = val[0][r] + o0;
+                        sum += val[NPX - 1][r];
+                        sum += o1;
+                        if (!(lane & 1) && y + 1 < p.H) dst[(size_t)((r & 3) + 8 * (r >> 2)) * Ho * Wo] = sum * 0.25f;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int px = 0; px < NPX; ++px) {
+                    const int y = y0 + wave * WROWS + px * PH + ty;
+                    float* dst = p.pool_out + ((size_t)b * p.N + n0 + co * 32 + 4 * khalf) * p.H * Wo +
+                                 (size_t)min(y, p.H - 1) * Wo + (x >> 1);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float sum = val[px][r] + __shfl_xor(val[px][r], 1, 64);
+                        if (!(lane & 1) && y < p.H) dst[(size_t)((r & 3) + 8 * (r >> 2)) * p.H * Wo] = sum * 0.5f;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---- single-tile kernel, double-buffered LDS (one barrier per chunk) --------------------------------------------------
+template <int TAPS, int NCO, int NPX, int PW, int FLAGS>
+__global__ __launch_bounds__(NTHREADS) void conv_kernel_db(ConvArgs p) {
     constexpr bool PRO = (FLAGS & F_PRO) != 0;
-    constexpr bool DB = (VAR & 1) != 0;  // double-buffered LDS, one barrier per chunk
     constexpr int KCA = (TAPS == 9) ? 8 : 16;
     using PA = Phase<TAPS, KCA, NCO, NPX, PW, PRO>;
     using PB = Phase<1, 16, NCO, NPX, PW, false>;
     constexpr int LDS_ONE = (FLAGS & F_PHASEB) ? MaxI<PA::LDS_FLOATS, PB::LDS_FLOATS>::v : PA::LDS_FLOATS;
-    constexpr int LDS_MAIN = DB ? 2 * LDS_ONE : LDS_ONE;
+    constexpr int LDS_MAIN = 2 * LDS_ONE;
     constexpr int PH = PA::PH, WROWS = PA::WROWS, PHT = PA::PHT, NT = PA::NT;
     constexpr bool EPI = (FLAGS & F_EPIACT) != 0;
 
@@ -276,10 +341,6 @@ __global__ __launch_bounds__(NTHREADS) void conv_kernel(ConvArgs p) {
     const int lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.z;
     const int n0 = blockIdx.y * NT;
-#ifdef LASS_CONV_DIAG
-    const long long k_c0 = clock64(), k_r0 = wall_clock64();
-    long long dsum[4] = {0, 0, 0, 0};
-#endif
     const int tiles_x = p.W / PW;
     const int y0 = (blockIdx.x / tiles_x) * PHT;
     const int x0 = (blockIdx.x % tiles_x) * PW;
@@ -317,72 +378,182 @@ __global__ __launch_bounds__(NTHREADS) void conv_kernel(ConvArgs p) {
     const float* sh = PRO ? p.pro_shift + (size_t)b * p.pro_shift_bs : nullptr;
     {
         PA ph;
-        if (DB)
-            ph.run_db(lds, LDS_ONE, p.in + (size_t)b * p.in_bs, p.Cin, HW, p.w, p.Nw, n0, sc, sh, acc, tid, y0, x0, p.H,
-                      p.W);
-        else
-            ph.run(lds, p.in + (size_t)b * p.in_bs, p.Cin, HW, p.w, p.Nw, n0, sc, sh, acc, tid, y0, x0, p.H, p.W);
-#ifdef LASS_CONV_DIAG
-        for (int i = 0; i < 4; ++i) dsum[i] += ph.diag[i];
-#endif
+        ph.run_db(lds, LDS_ONE, p.in + (size_t)b * p.in_bs, p.Cin, HW, p.w, p.Nw, n0, sc, sh, acc, tid, y0, x0, p.H,
+                  p.W);
     }
-#ifdef LASS_CONV_DIAG
-    const long long k_c1 = clock64();
-#endif
     if (FLAGS & F_PHASEB) {
         PB ph;
-        if (DB)
-            ph.run_db(lds, LDS_ONE, p.in2 + (size_t)b * p.in2_bs, p.Cin2, HW, p.w2, p.Nw, n0, nullptr, nullptr, acc,
-                      tid, y0, x0, p.H, p.W);
-        else
-            ph.run(lds, p.in2 + (size_t)b * p.in2_bs, p.Cin2, HW, p.w2, p.Nw, n0, nullptr, nullptr, acc, tid, y0, x0,
-                   p.H, p.W);
+        ph.run_db(lds, LDS_ONE, p.in2 + (size_t)b * p.in2_bs, p.Cin2, HW, p.w2, p.Nw, n0, nullptr, nullptr, acc, tid,
+                  y0, x0, p.H, p.W);
     }
 
-    // ---- epilogue: D row (register) = output channel, D col (lane&31) = pixel; stores only --------------------
+    // ---- epilogue ---------------------------------------------------------------------------------------------
+    if (FLAGS & F_TCONV) {
+        tconv_store<NCO, NPX, PW>(p, acc, b, n0, y0, x0, lane, wave);
+    } else {
+        store_tile<NCO, NPX, PW, (FLAGS & ~F_RES), false>(p, acc, nullptr, lds_es, lds_eh, b, n0, y0, x0, lane, wave);
+    }
+}
+
+// ---- single-tile kernel, single-buffered LDS (two barriers per chunk, highest occupancy) ------------------------------
+// Used for the 32-wide output tiles, the few-chunk layers and the 1-tap kernels.  Everything that has to come from HBM
+// before the next contraction can start is requested one contraction earlier: chunk c+1 during chunk c, the shortcut
+// phase's first chunk and the identity residual during the main phase's last chunk.
+// (A multi-tile variant with cross-tile prefetch was measured and brought nothing: on these layers the matrix pipe is
+// already ~90 % busy and the chip holds only ~1.9 GHz under their HBM + LDS load - see DESIGN.md.)
+template <int TAPS, int NCO, int NPX, int PW, int FLAGS>
+__global__ __launch_bounds__(NTHREADS) void conv_kernel_sb(ConvArgs p) {
+    constexpr bool PRO = (FLAGS & F_PRO) != 0;
+    constexpr bool HASB = (FLAGS & F_PHASEB) != 0;
+    constexpr bool EPI = (FLAGS & F_EPIACT) != 0;
+    constexpr bool BIAS = (FLAGS & F_BIAS) != 0;
+    constexpr bool RES = (FLAGS & F_RES) != 0;
+    constexpr bool RES_PF = RES && NCO == 1;  // residual prefetched into registers during the last chunk
+    constexpr int KCA = (TAPS == 9) ? 8 : 16;
+    using PA = Phase<TAPS, KCA, NCO, NPX, PW, PRO>;
+    using PB = Phase<1, 16, NCO, NPX, PW, false>;
+    constexpr int LDS_ONE = HASB ? MaxI<PA::LDS_FLOATS, PB::LDS_FLOATS>::v : PA::LDS_FLOATS;
+    constexpr int PH = PA::PH, WROWS = PA::WROWS, PHT = PA::PHT, NT = PA::NT;
+    constexpr int NTAB = (EPI ? 2 * NT : 0) + (BIAS ? NT : 0);
+
+    __shared__ __attribute__((aligned(16))) float lds[LDS_ONE + NTAB];
+    float* lds_es = lds + LDS_ONE;  // epilogue scale / shift for this block's NT output channels
+    float* lds_eh = lds_es + NT;
+    float* lds_bias = lds + LDS_ONE + (EPI ? 2 * NT : 0);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.z;
+    const int n0 = blockIdx.y * NT;
+    const int tiles_x = p.W / PW;
+    const int y0 = (blockIdx.x / tiles_x) * PHT, x0 = (blockIdx.x % tiles_x) * PW;
+    const int HW = p.H * p.W;
+    const int khalf = lane >> 5, j = lane & 31;
+    const int ty = j / PW, tx = j % PW;
+    const int x = x0 + tx;
+    const int nA = p.Cin / KCA;
+    const int nB = HASB ? p.Cin2 / 16 : 0;
+    const float* in_b = p.in + (size_t)b * p.in_bs;
+    const float* in2_b = HASB ? p.in2 + (size_t)b * p.in2_bs : nullptr;
+    const float* sc = PRO ? p.pro_scale : nullptr;
+    const float* sh = PRO ? p.pro_shift + (size_t)b * p.pro_shift_bs : nullptr;
+#ifdef LASS_CONV_DIAG
+    const long long k_c0 = clock64(), k_r0 = wall_clock64();
+    long long dsum[4] = {0, 0, 0, 0};
+#endif
+
+    if (EPI && tid < NT) {
+        lds_es[tid] = p.epi_scale[n0 + tid];
+        lds_eh[tid] = p.epi_shift[(size_t)b * p.epi_shift_bs + n0 + tid];
+    }
+    if (BIAS && tid < NT) lds_bias[tid] = p.bias[n0 + tid];
+
+    PA pa;
+    PB pb;
+    auto loadA = [&](int c) {
+        pa.load(in_b + (size_t)c * KCA * HW, HW, p.w + (size_t)c * KCA * TAPS * p.Nw + n0, p.Nw, sc + c * KCA,
+                sh + c * KCA, tid);
+    };
+    auto loadB = [&](int c) {
+        pb.load(in2_b + (size_t)c * 16 * HW, HW, p.w2 + (size_t)c * 16 * p.Nw + n0, p.Nw, nullptr, nullptr, tid);
+    };
+
+    pa.init(tid, y0, x0, p.H, p.W);
+    loadA(0);
+    __syncthreads();  // tables visible
+    pa.store(lds, tid);
+    __syncthreads();
+#ifdef LASS_CONV_DIAG
+    const long long k_c1 = clock64();  // end of the block prologue
+#endif
+
+    f32x16 acc[NCO][NPX];
 #pragma unroll
-    for (int co = 0; co < NCO; ++co) {
+    for (int co = 0; co < NCO; ++co)
+#pragma unroll
+        for (int px = 0; px < NPX; ++px)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                acc[co][px][r] = BIAS ? lds_bias[co * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf] : 0.f;
+
+    // ---- main phase, all chunks but the last
+    for (int ch = 0; ch + 1 < nA; ++ch) {
+#ifdef LASS_CONV_DIAG
+        const long long t0 = clock64();
+#endif
+        loadA(ch + 1);
+        PA::compute(lds, acc, lane, wave);
+#ifdef LASS_CONV_DIAG
+        const long long t1 = clock64();
+#endif
+        __syncthreads();
+#ifdef LASS_CONV_DIAG
+        const long long t2 = clock64();
+#endif
+        pa.store(lds, tid);
+#ifdef LASS_CONV_DIAG
+        const long long t3 = clock64();
+#endif
+        __syncthreads();
+#ifdef LASS_CONV_DIAG
+        dsum[0] += t1 - t0; dsum[1] += t2 - t1; dsum[2] += t3 - t2; dsum[3] += clock64() - t3;
+#endif
+    }
+    // ---- last chunk of the main phase: prefetch what the shortcut phase / the epilogue need
+    float rtmp[RES_PF ? NPX : 1][16];
+    if (HASB) {
+        pb.init(tid, y0, x0, p.H, p.W);
+        loadB(0);
+    }
+    if (RES_PF) {
 #pragma unroll
         for (int px = 0; px < NPX; ++px) {
-            const int y = y0 + wave * WROWS + px * PH + ty;
-            if (y >= p.H) continue;
-            if (FLAGS & F_TCONV) {
-                // n = co_real*(uh*uw) + a*uw + bb, uw == 2: registers (r, r+1), r even, are bb = 0/1 of one (co_real, a)
-                const int uhw = p.up_h * 2;
-                const size_t oHW = (size_t)HW * uhw;
-                const int oW = p.W * 2;
+            const int y = min(y0 + wave * WROWS + px * PH + ty, p.H - 1);
+            const float* src = p.res + (size_t)b * p.res_bs + (size_t)(n0 + 4 * khalf) * HW + (size_t)y * p.W + x;
 #pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    const int n = n0 + co * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                    const int co_real = n / uhw, a = (n % uhw) >> 1;
-                    float2 o = make_float2(acc[co][px][r], acc[co][px][r + 1]);
-                    float* dst = p.out + (size_t)b * p.out_bs + co_real * oHW + (size_t)(y * p.up_h + a) * oW + x * 2;
-                    *reinterpret_cast<float2*>(dst) = o;
-                }
-            } else {
-                float* dst =
-                    p.out + (size_t)b * p.out_bs + (size_t)(n0 + co * 32 + 4 * khalf) * HW + (size_t)y * p.W + x;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int nl = (r & 3) + 8 * (r >> 2);  // + co*32 + 4*khalf
-                    float v = acc[co][px][r];
-                    if (EPI) v = leaky(v * lds_es[co * 32 + 4 * khalf + nl] + lds_eh[co * 32 + 4 * khalf + nl]);
-                    dst[(size_t)nl * HW] = v;
-                }
-            }
+            for (int r = 0; r < 16; ++r) rtmp[px][r] = src[(size_t)((r & 3) + 8 * (r >> 2)) * HW];
         }
     }
+    PA::compute(lds, acc, lane, wave);
+    // ---- shortcut phase (1x1 over the raw block input)
+    if (HASB) {
+        __syncthreads();
+        pb.store(lds, tid);
+        __syncthreads();
+        for (int ch = 0; ch + 1 < nB; ++ch) {
+            loadB(ch + 1);
+            PB::compute(lds, acc, lane, wave);
+            __syncthreads();
+            pb.store(lds, tid);
+            __syncthreads();
+        }
+        PB::compute(lds, acc, lane, wave);
+    }
+#ifdef LASS_CONV_DIAG
+    const long long k_c2 = clock64();
+#endif
+    // ---- epilogue
+    if (FLAGS & F_TCONV)
+        tconv_store<NCO, NPX, PW>(p, acc, b, n0, y0, x0, lane, wave);
+    else
+        store_tile<NCO, NPX, PW, FLAGS, RES_PF>(p, acc, rtmp, lds_es, lds_eh, b, n0, y0, x0, lane, wave);
 #ifdef LASS_CONV_DIAG
     if (p.dbg && tid == 0) {
-        const long long k_c2 = clock64(), k_r2 = wall_clock64();
+        const long long k_c3 = clock64(), k_r3 = wall_clock64();
         long long* d = p.dbg + 8 * ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
         d[0] = dsum[0]; d[1] = dsum[1]; d[2] = dsum[2]; d[3] = dsum[3];
-        d[4] = k_c1 - k_c0;   // start .. end of main K phase
-        d[5] = k_c2 - k_c0;   // whole block, shader cycles
-        d[6] = k_r2 - k_r0;   // whole block, 100 MHz ticks
+        d[4] = k_c1 - k_c0;   // prologue
+        d[5] = k_c3 - k_c0;   // whole block, shader cycles
+        d[6] = k_r3 - k_r0;   // whole block, 100 MHz ticks
         d[7] = k_r0;
+        (void)k_c2;
     }
 #endif
+}
+
+int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
 }
 
 // -1 = automatic (double-buffered LDS for the 64-wide 3x3 tiles, where it measured 1-9 % faster; single-buffered for
@@ -439,24 +610,44 @@ hipError_t launch_one(const ConvArgs& p0, hipStream_t stream) {
     } rep{dbuf, nblk, p};
 #endif
     const int var = conv_variant();
-    const bool db = var < 0 ? (TAPS == 9 && NCO == 2 && PW == 32) : (var & 1) != 0;
-    if (db)
-        hipLaunchKernelGGL((conv_kernel<TAPS, NCO, NPX, PW, FLAGS, 1>), grid, dim3(NTHREADS), 0, stream, p);
-    else
-        hipLaunchKernelGGL((conv_kernel<TAPS, NCO, NPX, PW, FLAGS, 0>), grid, dim3(NTHREADS), 0, stream, p);
+    const int kc = TAPS == 9 ? 8 : 16;
+    const int nchunks = p.Cin / kc;
+    // double-buffered kernel (one barrier per chunk) for the 64-wide tiles with many chunks, where it measured 1-9 %
+    // faster; the single-buffered kernel (higher occupancy) everywhere else
+    const bool db = var < 0 ? (TAPS == 9 && NCO == 2 && PW == 32 && nchunks >= 16 && !(FLAGS & F_RES))
+                            : ((var & 1) != 0 && !(FLAGS & F_RES));
+    if (db) {
+        if constexpr (TAPS == 9 && NCO == 2 && PW == 32 && !(FLAGS & F_RES))
+            hipLaunchKernelGGL((conv_kernel_db<TAPS, NCO, NPX, PW, FLAGS>), grid, dim3(NTHREADS), 0, stream, p);
+    } else {
+        hipLaunchKernelGGL((conv_kernel_sb<TAPS, NCO, NPX, PW, FLAGS>), grid, dim3(NTHREADS), 0, stream, p);
+    }
     return hipGetLastError();
 }
 
+// Tile geometry per layer shape.  Wave tile = NCO x NPX MFMA tiles of 32 couts x 32 pixels; block = 4 waves stacked
+// over rows.  The bottom of the U-Net (W <= 16, 384 channels, a few thousand pixels per batch) needs small tiles to
+// produce enough workgroups for 256 CUs.
 template <int TAPS, int FLAGS>
 hipError_t launch_geom(const ConvArgs& p, hipStream_t stream) {
+    static const int small_env = env_int("LASS_SMALL", -1);
+    // measured (B=16): 3x3 at W=16 -> 32-cout x 32-px wave tiles in 8-row blocks; 3x3 at W=8 -> 32-cout tiles;
+    // the 1-tap transposed convs keep the 64-cout tiles
+    const int small = small_env >= 0 ? small_env : (TAPS == 9 ? (p.W == 16 ? 3 : 2) : 0);
     const int pw = p.W >= 32 ? 32 : p.W;
     if (pw == 32) {
         if (p.N % 64 == 0) return launch_one<TAPS, 2, 2, 32, FLAGS>(p, stream);
         return launch_one<TAPS, 1, 2, 32, FLAGS>(p, stream);
     }
     if (p.N % 64 != 0) return hipErrorInvalidValue;
-    if (pw == 16) return launch_one<TAPS, 2, 2, 16, FLAGS>(p, stream);
-    if (pw == 8) return launch_one<TAPS, 2, 2, 8, FLAGS>(p, stream);
+    if (pw == 16) {
+        if (small == 3) return launch_one<TAPS, 1, 1, 16, FLAGS>(p, stream);
+        return launch_one<TAPS, 2, 2, 16, FLAGS>(p, stream);
+    }
+    if (pw == 8) {
+        if (small == 2) return launch_one<TAPS, 1, 2, 8, FLAGS>(p, stream);
+        return launch_one<TAPS, 2, 2, 8, FLAGS>(p, stream);
+    }
     return hipErrorInvalidValue;
 }
 

@@ -37,6 +37,8 @@ struct ConvArgs {
     int B = 0, H = 0, W = 0;
     int N = 0;  // output channels computed by this launch (GEMM rows)
     int up_h = 1;  // TCONV: vertical stride (1 or 2); horizontal stride is always 2
+    float* pool_out = nullptr;  // fused avg-pool of the output: (B, N, H/pool_h, W/2) dense
+    int pool_h = 2;              // vertical pool factor (1 or 2); horizontal is 2
     long long* dbg = nullptr;  // diagnostic builds (-DLASS_CONV_DIAG) only: 8 int64 per block
 };
 
