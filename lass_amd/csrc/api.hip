@@ -78,6 +78,7 @@ struct lass_ctx {
     int dec_site[6] = {0};           // decoder_blockN->beta1
     std::vector<void*> owned;        // derived device buffers to free
     // profiling
+    bool fuse_preconv = true;  // LASS_FUSE_PRECONV=0 materialises pre_conv's output with its own kernel
     bool fuse_pool = true;  // LASS_FUSE_POOL=0 selects the stand-alone pool kernel (A/B + parity of both paths)
     bool profiling = false;
     std::vector<ProfEntry> prof;
@@ -282,8 +283,10 @@ void prof_collect(lass_ctx* c) {
 // ---- one residual block ---------------------------------------------------------------------------------------------
 // x: (B,cin,H,W) batch stride x_bs; out: batch stride out_bs (may be a channel slice of a concat buffer).
 // pool_out (optional): the block's avg-pooled output (B,cout,H/pool_h,W/2), produced by conv2's epilogue.
+// x0 (optional, encoder_block1 only): the block input is pre_conv(x0) and is formed on the fly - x is then ignored.
 int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int B, int H, int W, const float* shift,
-                 float* a2, float* out, long out_bs, hipStream_t st, float* pool_out = nullptr, int pool_h = 2) {
+                 float* a2, float* out, long out_bs, hipStream_t st, float* pool_out = nullptr, int pool_h = 2,
+                 const float* x0 = nullptr) {
     const Site& s1 = c->sites[rb.s1];
     const Site& s2 = c->sites[rb.s2];
     const long HW = (long)H * W;
@@ -292,9 +295,13 @@ int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int
     p.pro_scale = c->bn_scale + s1.off; p.pro_shift = shift + s1.off; p.pro_shift_bs = c->n_shift;
     p.epi_scale = c->bn_scale + s2.off; p.epi_shift = shift + s2.off; p.epi_shift_bs = c->n_shift;
     p.out = a2; p.out_bs = rb.cout * HW; p.B = B; p.H = H; p.W = W;
+    if (x0) {
+        p.in = x0; p.in_bs = HW;
+        p.pre_w = rawp(c, "base.pre_conv.weight"); p.pre_b = rawp(c, "base.pre_conv.bias");
+    }
     {
         ProfScope ps(c, st, P_CONV3X3);
-        HIP_TRY(c, lass_launch_conv(CONV1_ACT, p, st));
+        HIP_TRY(c, lass_launch_conv(x0 ? CONV1_ACT_PRE : CONV1_ACT, p, st));
     }
     ConvArgs q;
     q.in = a2; q.in_bs = rb.cout * HW; q.Cin = rb.cout; q.w = rb.w2; q.Nw = rb.cout; q.N = rb.cout;
@@ -303,7 +310,11 @@ int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int
     ProfScope ps(c, st, P_CONV3X3);
     if (rb.cin == rb.cout) {
         q.res = x; q.res_bs = x_bs;
-        HIP_TRY(c, lass_launch_conv(CONV2_IDENT, q, st));
+        if (x0) {
+            q.res = x0; q.res_bs = HW;
+            q.pre_w = rawp(c, "base.pre_conv.weight"); q.pre_b = rawp(c, "base.pre_conv.bias");
+        }
+        HIP_TRY(c, lass_launch_conv(x0 ? CONV2_IDENT_PRE : CONV2_IDENT, q, st));
     } else {
         q.in2 = x; q.in2_bs = x_bs; q.Cin2 = rb.cin; q.w2 = rb.wsc; q.bias = rb.bsc;
         HIP_TRY(c, lass_launch_conv(CONV2_SHORTCUT, q, st));
@@ -421,6 +432,7 @@ int lass_create(lass_ctx** out, int device_id) {
     lass_ctx* c = new lass_ctx();
     c->device = device_id;
     if (const char* e = getenv("LASS_FUSE_POOL")) c->fuse_pool = atoi(e) != 0;
+    if (const char* e = getenv("LASS_FUSE_PRECONV")) c->fuse_preconv = atoi(e) != 0;
     c->prof.resize(P_COUNT);
     for (int i = 0; i < P_COUNT; ++i) c->prof[i].name = kProfNames[i];
     build_arch(c);
@@ -670,7 +682,8 @@ int lass_separate(lass_ctx* c, const float* mixture, const float* condition, flo
         ProfScope ps(c, st, P_FILM);
         HIP_TRY(c, lass_launch_film(condition, B, c->film_W, c->film_b, c->bn_base, c->n_shift, shift, st));
     }
-    {
+    // pre_conv (resunet.py:555) is normally never materialised: encoder_block1 forms it from x0 while staging
+    if (!c->fuse_preconv) {
         ProfScope ps(c, st, P_PRECONV);
         HIP_TRY(c, lass_launch_preconv(F(pl.x0), rawp(c, "base.pre_conv.weight"), rawp(c, "base.pre_conv.bias"), B,
                                        kPreCh, (long)Tp * LASS_FCROP, F(pl.xpre), st));
@@ -693,7 +706,8 @@ int lass_separate(lass_ctx* c, const float* mixture, const float* condition, flo
         // F.avg_pool2d (resunet.py:197) is fused into conv2's epilogue; W >= 16 at every pooled level
         const bool fuse_pool = i < 6 && c->fuse_pool && (H % kEnc[i].dh) == 0;
         r = run_resblock(c, rb, x, rb.cin * HW, B, H, W, shift, F(pl.a2), o, o_bs, st,
-                         fuse_pool ? F(pl.pool[i]) : nullptr, kEnc[i].dh);
+                         fuse_pool ? F(pl.pool[i]) : nullptr, kEnc[i].dh,
+                         (i == 0 && c->fuse_preconv) ? F(pl.x0) : nullptr);
         if (r) return r;
         if (i < 6) {
             if (!fuse_pool) {

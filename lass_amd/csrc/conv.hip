@@ -34,6 +34,8 @@ constexpr int F_BIAS = 4;    // + bias[n]            (as initial accumulator)
 constexpr int F_RES = 8;     // + res[b][n][y][x]    (as initial accumulator)
 constexpr int F_EPIACT = 16; // epilogue: leaky(v*scale[n] + shift[b][n])
 constexpr int F_TCONV = 32;  // n = (co, a, bb); scatter to (y*uh+a, x*uw+bb)
+constexpr int F_PRECONV = 64;   // input is the 1-channel x0; channel c = pre_w[c]*x0 + pre_b[c] is formed while staging
+constexpr int F_RESPRE = 128;   // with F_RES: the residual is pre_w[n]*x0 + pre_b[n] (never materialised)
 
 constexpr int NTHREADS = 256;
 
@@ -43,7 +45,7 @@ __device__ __forceinline__ float leaky(float v) { return fmaxf(v, 0.01f * v); } 
 // in LDS; the registers of chunk c+1 are loaded from global memory while chunk c is contracted.
 // Input staging walks the chunk in groups of G channels (G*CH_ELEMS elements, NPASS passes of 256 threads), so the
 // channel of an element is (group, u >= CH_ELEMS): wave-uniform up to one select.
-template <int TAPS, int KC, int NCO, int NPX, int PW, bool PRO>
+template <int TAPS, int KC, int NCO, int NPX, int PW, bool PRO, bool PRE = false>
 struct Phase {
     static constexpr int PH = 32 / PW;
     static constexpr int WROWS = NPX * PH;
@@ -72,6 +74,8 @@ struct Phase {
     float v[NGRP][NPASS];   // prefetched input elements
     float4 wv[NWLD];        // prefetched weights
     float psc[KC], psh[KC]; // wave-uniform prologue scale / shift of the prefetched chunk (SGPRs)
+    float pcw[KC], pcb[KC]; // PRE: pre_conv weight / bias of the prefetched chunk's channels (resunet.py:555)
+    float x0v[NPASS];       // PRE: the single-channel input at this thread's positions (same for every channel)
 
     __device__ __forceinline__ static int upos(int tid, int k) {  // element index within a channel group (clamped:
         const int u = tid + k * NTHREADS;                        // surplus threads of the last pass duplicate the
@@ -95,12 +99,27 @@ struct Phase {
     }
 
     // in_c0: channel c0 of this clip; w_c0: Wt[c0][0][n0]; sc/sh: prologue tables at channel c0 (PRO only)
+    // PRE: fetch x0 once per tile (goff's channel-local part must be dropped: there is one plane only)
+    __device__ __forceinline__ void load_x0(const float* __restrict__ x0_b, int HW) {
+#pragma unroll
+        for (int k = 0; k < NPASS; ++k) x0v[k] = x0_b[goff[k] >= HW ? goff[k] - HW : goff[k]];
+    }
+    __device__ __forceinline__ void load_pre(const float* __restrict__ pw, const float* __restrict__ pb) {
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            pcw[c] = pw[c];
+            pcb[c] = pb[c];
+        }
+    }
+
     __device__ __forceinline__ void load(const float* __restrict__ in_c0, int HW, const float* __restrict__ w_c0,
                                          int Nw, const float* __restrict__ sc, const float* __restrict__ sh, int tid) {
+        if (!PRE) {
 #pragma unroll
-        for (int q = 0; q < NGRP; ++q)
+            for (int q = 0; q < NGRP; ++q)
 #pragma unroll
-            for (int k = 0; k < NPASS; ++k) v[q][k] = in_c0[(size_t)q * G * HW + goff[k]];
+                for (int k = 0; k < NPASS; ++k) v[q][k] = in_c0[(size_t)q * G * HW + goff[k]];
+        }
 #pragma unroll
         for (int i = 0; i < NWLD; ++i) {
             const int e0 = tid + i * NTHREADS;  // float4 index into [KC*TAPS][NT/4]
@@ -123,7 +142,11 @@ struct Phase {
 #pragma unroll
             for (int k = 0; k < NPASS; ++k) {
                 const int u = upos(tid, k);
-                float t = v[q][k];
+                float t = PRE ? 0.f : v[q][k];
+                if (PRE) {
+                    const bool hi0 = (G == 2) && (u >= CH_ELEMS);
+                    t = x0v[k] * (hi0 ? pcw[q * G + G - 1] : pcw[q * G]) + (hi0 ? pcb[q * G + G - 1] : pcb[q * G]);
+                }
                 if (PRO) {
                     const bool hi = (G == 2) && (u >= CH_ELEMS);
                     const float s = hi ? psc[q * G + G - 1] : psc[q * G];
@@ -409,17 +432,22 @@ __global__ __launch_bounds__(NTHREADS) void conv_kernel_sb(ConvArgs p) {
     constexpr bool BIAS = (FLAGS & F_BIAS) != 0;
     constexpr bool RES = (FLAGS & F_RES) != 0;
     constexpr bool RES_PF = RES && NCO == 1;  // residual prefetched into registers during the last chunk
+    constexpr bool PRE = (FLAGS & F_PRECONV) != 0;
+    constexpr bool RESPRE = (FLAGS & F_RESPRE) != 0;
+    static_assert(!RESPRE || RES_PF, "x0-derived residual needs the register-prefetch path");
     constexpr int KCA = (TAPS == 9) ? 8 : 16;
-    using PA = Phase<TAPS, KCA, NCO, NPX, PW, PRO>;
+    using PA = Phase<TAPS, KCA, NCO, NPX, PW, PRO, PRE>;
     using PB = Phase<1, 16, NCO, NPX, PW, false>;
     constexpr int LDS_ONE = HASB ? MaxI<PA::LDS_FLOATS, PB::LDS_FLOATS>::v : PA::LDS_FLOATS;
     constexpr int PH = PA::PH, WROWS = PA::WROWS, PHT = PA::PHT, NT = PA::NT;
-    constexpr int NTAB = (EPI ? 2 * NT : 0) + (BIAS ? NT : 0);
+    constexpr int NTAB = (EPI ? 2 * NT : 0) + (BIAS ? NT : 0) + (RESPRE ? 2 * NT : 0);
 
     __shared__ __attribute__((aligned(16))) float lds[LDS_ONE + NTAB];
     float* lds_es = lds + LDS_ONE;  // epilogue scale / shift for this block's NT output channels
     float* lds_eh = lds_es + NT;
     float* lds_bias = lds + LDS_ONE + (EPI ? 2 * NT : 0);
+    float* lds_rw = lds + LDS_ONE + (EPI ? 2 * NT : 0) + (BIAS ? NT : 0);  // RESPRE: pre_conv weight / bias of the
+    float* lds_rb = lds_rw + NT;                                          // block's output channels
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -447,18 +475,24 @@ __global__ __launch_bounds__(NTHREADS) void conv_kernel_sb(ConvArgs p) {
         lds_eh[tid] = p.epi_shift[(size_t)b * p.epi_shift_bs + n0 + tid];
     }
     if (BIAS && tid < NT) lds_bias[tid] = p.bias[n0 + tid];
+    if (RESPRE && tid < NT) {
+        lds_rw[tid] = p.pre_w[n0 + tid];
+        lds_rb[tid] = p.pre_b[n0 + tid];
+    }
 
     PA pa;
     PB pb;
     auto loadA = [&](int c) {
         pa.load(in_b + (size_t)c * KCA * HW, HW, p.w + (size_t)c * KCA * TAPS * p.Nw + n0, p.Nw, sc + c * KCA,
                 sh + c * KCA, tid);
+        if (PRE) pa.load_pre(p.pre_w + c * KCA, p.pre_b + c * KCA);
     };
     auto loadB = [&](int c) {
         pb.load(in2_b + (size_t)c * 16 * HW, HW, p.w2 + (size_t)c * 16 * p.Nw + n0, p.Nw, nullptr, nullptr, tid);
     };
 
     pa.init(tid, y0, x0, p.H, p.W);
+    if (PRE) pa.load_x0(in_b, HW);
     loadA(0);
     __syncthreads();  // tables visible
     pa.store(lds, tid);
@@ -509,6 +543,15 @@ __global__ __launch_bounds__(NTHREADS) void conv_kernel_sb(ConvArgs p) {
 #pragma unroll
         for (int px = 0; px < NPX; ++px) {
             const int y = min(y0 + wave * WROWS + px * PH + ty, p.H - 1);
+            if (RESPRE) {  // residual = pre_conv(x0) at this pixel: one load, 16 FMAs (resunet.py:555,165)
+                const float xv = p.res[(size_t)b * p.res_bs + (size_t)y * p.W + x];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int nl = 4 * khalf + (r & 3) + 8 * (r >> 2);
+                    rtmp[px][r] = xv * lds_rw[nl] + lds_rb[nl];
+                }
+                continue;
+            }
             const float* src = p.res + (size_t)b * p.res_bs + (size_t)(n0 + 4 * khalf) * HW + (size_t)y * p.W + x;
 #pragma unroll
             for (int r = 0; r < 16; ++r) rtmp[px][r] = src[(size_t)((r & 3) + 8 * (r >> 2)) * HW];
@@ -677,6 +720,15 @@ hipError_t lass_launch_conv(ConvKind kind, const ConvArgs& p, hipStream_t stream
         case CONV2_SHORTCUT:  // 3x3 over pre-activated input, + 1x1(in2) + bias
             if (!conv_args_ok(p, 9, true) || !p.in2 || !p.w2 || !p.bias) return hipErrorInvalidValue;
             return launch_geom<9, F_PHASEB | F_BIAS>(p, stream);
+        case CONV1_ACT_PRE:  // encoder_block1.conv1 reading x0 directly (pre_conv fused into the staging)
+            if (!conv_args_ok(p, 9, false) || !p.pro_scale || !p.pro_shift || !p.epi_scale || !p.epi_shift ||
+                !p.pre_w || !p.pre_b || p.N != 32 || p.W < 32)
+                return hipErrorInvalidValue;
+            return launch_one<9, 1, 2, 32, F_PRO | F_EPIACT | F_PRECONV>(p, stream);
+        case CONV2_IDENT_PRE:  // encoder_block1.conv2 with the residual recomputed from x0
+            if (!conv_args_ok(p, 9, false) || !p.res || !p.pre_w || !p.pre_b || p.N != 32 || p.W < 32)
+                return hipErrorInvalidValue;
+            return launch_one<9, 1, 2, 32, F_RES | F_RESPRE>(p, stream);
         case TCONV_ACT:  // kernel==stride transposed conv with prologue act
             if (!conv_args_ok(p, 1, false) || !p.pro_scale || !p.pro_shift || (p.up_h != 1 && p.up_h != 2))
                 return hipErrorInvalidValue;

@@ -37,12 +37,14 @@ struct ConvArgs {
     int B = 0, H = 0, W = 0;
     int N = 0;  // output channels computed by this launch (GEMM rows)
     int up_h = 1;  // TCONV: vertical stride (1 or 2); horizontal stride is always 2
+    const float* pre_w = nullptr;  // pre_conv (1x1, 1 -> 32) weight / bias for the *_PRE kinds
+    const float* pre_b = nullptr;
     float* pool_out = nullptr;  // fused avg-pool of the output: (B, N, H/pool_h, W/2) dense
     int pool_h = 2;              // vertical pool factor (1 or 2); horizontal is 2
     long long* dbg = nullptr;  // diagnostic builds (-DLASS_CONV_DIAG) only: 8 int64 per block
 };
 
-enum ConvKind { CONV1_ACT = 0, CONV2_IDENT = 1, CONV2_SHORTCUT = 2, TCONV_ACT = 3 };
+enum ConvKind { CONV1_ACT = 0, CONV2_IDENT = 1, CONV2_SHORTCUT = 2, TCONV_ACT = 3, CONV1_ACT_PRE = 4, CONV2_IDENT_PRE = 5 };
 
 hipError_t lass_launch_conv(ConvKind kind, const ConvArgs& p, hipStream_t stream);
 

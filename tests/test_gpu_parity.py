@@ -258,6 +258,20 @@ def test_silence_and_edge_lengths(model, oracle_sd):
         assert _rms(out.cpu() - ref) < 2e-6
 
 
+def test_long_form_clip_config5(model, oracle_sd):
+    """BASELINE configs[4] input shape: one 30 s clip at 32 kHz (L = 960000, T = 6001 -> 6016) through the same
+    single-STFT trunk (the reference's multi-STFT model is not runnable).  Whole-clip forward vs the oracle."""
+    from oracle import resunet as orr
+    L = 960000
+    segs = [synthetic.make_mixtures(1, 160000, first=20 + i)[1][0] for i in range(6)]
+    mix = torch.from_numpy(np.concatenate(segs)[:L].astype(np.float32))[None, None, :]
+    cond = torch.from_numpy(synthetic.make_condition(1))
+    out = model({"mixture": mix.to(DEV), "condition": cond.to(DEV)})["waveform"]
+    assert out.shape == (1, 1, L) and torch.isfinite(out).all()
+    ref = orr.forward(oracle_sd, {"mixture": mix, "condition": cond})["waveform"]
+    assert _rms(out.cpu() - ref) < 3e-6
+
+
 def test_chunk_inference_vs_golden(model, golden_dir):
     g = np.load(os.path.join(golden_dir, "g3_chunk.npz"))
     segs = [synthetic.make_mixtures(1, 160000, first=10 + i)[1][0] for i in range(3)]
