@@ -42,6 +42,19 @@ def host_cores() -> int:
     return min(n, 16)
 
 
+def pmc_traffic():
+    """HBM bytes per conv3x3 launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
+    command (profiles/rNN/conv_traffic.json, made by tools/traffic_summary.py); bench.py itself cannot read PMCs."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "conv_traffic.json")))
+    if not files:
+        return None, None
+    d = json.load(open(files[-1]))
+    return d.get("traffic_bytes_per_launch"), {"source": os.path.relpath(files[-1], ROOT),
+                                               "raw_bytes_per_launch": d.get("traffic_bytes_per_launch_raw"),
+                                               "note": d.get("note")}
+
+
 def cpu_baseline(sd, length, seconds_budget=20.0):
     """The oracle (CPU restatement of the reference path) timed on this box's host cores: a bounded sample of the same
     workload (batch-1 forwards of 10 s clips until ~seconds_budget of CPU time is spent)."""
@@ -139,6 +152,7 @@ def main():
         ms, launches = prof["conv3x3_mfma"]
         per_step_ms = ms / args.steps
         achieved = conv_flops / (per_step_ms * 1e-3) / 1e12 if per_step_ms > 0 else 0.0
+        traffic, traffic_meta = pmc_traffic() if (B, L) == (16, 160000) else (None, None)
         res = {
             "metric": "clips/sec (10s@16kHz)", "value": world * B * args.steps / dt, "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -149,7 +163,8 @@ def main():
             "realtime_factor": world * B * args.steps / dt * (L / 16000.0),
             "roofline": {"bound": "mfma", "kernel": "conv3x3_mfma (3x3 convs + fused 1x1 shortcuts, f32 MFMA)",
                          "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                         "traffic_meta": traffic_meta,
                          "launches_per_step": launches / args.steps, "avg_launch_ms": ms / max(1, launches),
                          "algorithmic_gflop_per_step": conv_flops / 1e9,
                          "whole_step_tflops": total_flops / (dt / args.steps) / 1e12},
