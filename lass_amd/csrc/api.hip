@@ -49,6 +49,7 @@ struct ResBlock {  // one ConvBlockRes
     int cin = 0, cout = 0;
     int s1 = -1, s2 = -1;  // site indices
     float *w1 = nullptr, *w2 = nullptr, *wsc = nullptr;  // re-laid-out
+    float *u1 = nullptr, *u2 = nullptr, *usc = nullptr;  // Winograd-domain copies (when enabled)
     const float* bsc = nullptr;                         // raw shortcut bias
 };
 
@@ -78,6 +79,7 @@ struct lass_ctx {
     int dec_site[6] = {0};           // decoder_blockN->beta1
     std::vector<void*> owned;        // derived device buffers to free
     // profiling
+    bool wino = true;          // Winograd F(2x2,3x3) kernels for the 3x3 convs at W >= 32 (LASS_WINO=0: direct only)
     bool fuse_preconv = true;  // LASS_FUSE_PRECONV=0 materialises pre_conv's output with its own kernel
     bool fuse_pool = true;  // LASS_FUSE_POOL=0 selects the stand-alone pool kernel (A/B + parity of both paths)
     bool profiling = false;
@@ -299,14 +301,21 @@ int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int
         p.in = x0; p.in_bs = HW;
         p.pre_w = rawp(c, "base.pre_conv.weight"); p.pre_b = rawp(c, "base.pre_conv.bias");
     }
+    p.w_wino = rb.u1;
+    const bool wino1 = c->wino && !x0 && rb.u1 && lass_wino_supported(p);
     {
         ProfScope ps(c, st, P_CONV3X3);
-        HIP_TRY(c, lass_launch_conv(x0 ? CONV1_ACT_PRE : CONV1_ACT, p, st));
+        if (wino1)
+            HIP_TRY(c, lass_launch_wino(CONV1_ACT, p, st));
+        else
+            HIP_TRY(c, lass_launch_conv(x0 ? CONV1_ACT_PRE : CONV1_ACT, p, st));
     }
     ConvArgs q;
     q.in = a2; q.in_bs = rb.cout * HW; q.Cin = rb.cout; q.w = rb.w2; q.Nw = rb.cout; q.N = rb.cout;
     q.out = out; q.out_bs = out_bs; q.B = B; q.H = H; q.W = W;
     q.pool_out = pool_out; q.pool_h = pool_h;
+    q.w_wino = rb.u2; q.w2_wino = rb.usc;
+    const bool wino2 = c->wino && !x0 && rb.u2 && lass_wino_supported(q);
     ProfScope ps(c, st, P_CONV3X3);
     if (rb.cin == rb.cout) {
         q.res = x; q.res_bs = x_bs;
@@ -314,10 +323,16 @@ int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int
             q.res = x0; q.res_bs = HW;
             q.pre_w = rawp(c, "base.pre_conv.weight"); q.pre_b = rawp(c, "base.pre_conv.bias");
         }
-        HIP_TRY(c, lass_launch_conv(x0 ? CONV2_IDENT_PRE : CONV2_IDENT, q, st));
+        if (wino2)
+            HIP_TRY(c, lass_launch_wino(CONV2_IDENT, q, st));
+        else
+            HIP_TRY(c, lass_launch_conv(x0 ? CONV2_IDENT_PRE : CONV2_IDENT, q, st));
     } else {
         q.in2 = x; q.in2_bs = x_bs; q.Cin2 = rb.cin; q.w2 = rb.wsc; q.bias = rb.bsc;
-        HIP_TRY(c, lass_launch_conv(CONV2_SHORTCUT, q, st));
+        if (wino2)
+            HIP_TRY(c, lass_launch_wino(CONV2_SHORTCUT, q, st));
+        else
+            HIP_TRY(c, lass_launch_conv(CONV2_SHORTCUT, q, st));
     }
     return 0;
 }
@@ -431,6 +446,7 @@ int lass_create(lass_ctx** out, int device_id) {
     }
     lass_ctx* c = new lass_ctx();
     c->device = device_id;
+    if (const char* e = getenv("LASS_WINO")) c->wino = atoi(e) != 0;
     if (const char* e = getenv("LASS_FUSE_POOL")) c->fuse_pool = atoi(e) != 0;
     if (const char* e = getenv("LASS_FUSE_PRECONV")) c->fuse_preconv = atoi(e) != 0;
     c->prof.resize(P_COUNT);
@@ -547,6 +563,13 @@ int lass_finalize(lass_ctx* c, int compute_mode) {
             return LASS_ERR_HIP;
         HIP_TRY(c, lass_launch_relayout_conv(w1, rb.cout, rb.cin, 9, rb.w1, st));
         HIP_TRY(c, lass_launch_relayout_conv(w2, rb.cout, rb.cout, 9, rb.w2, st));
+        rb.u1 = rb.u2 = rb.usc = nullptr;
+        if (c->wino) {
+            if (dev_alloc(c, &rb.u1, (size_t)16 * rb.cout * rb.cin) || dev_alloc(c, &rb.u2, (size_t)16 * rb.cout * rb.cout))
+                return LASS_ERR_HIP;
+            HIP_TRY(c, lass_launch_wino_weights(w1, rb.cout, rb.cin, rb.u1, st));
+            HIP_TRY(c, lass_launch_wino_weights(w2, rb.cout, rb.cout, rb.u2, st));
+        }
         rb.wsc = nullptr;
         rb.bsc = nullptr;
         if (rb.cin != rb.cout) {
@@ -555,6 +578,10 @@ int lass_finalize(lass_ctx* c, int compute_mode) {
             if (dev_alloc(c, &rb.wsc, (size_t)rb.cout * rb.cin)) return LASS_ERR_HIP;
             HIP_TRY(c, lass_launch_relayout_conv(ws, rb.cout, rb.cin, 1, rb.wsc, st));
             rb.bsc = bs;
+            if (c->wino) {
+                if (dev_alloc(c, &rb.usc, (size_t)4 * rb.cout * rb.cin)) return LASS_ERR_HIP;
+                HIP_TRY(c, lass_launch_wino_shortcut_weights(ws, rb.cout, rb.cin, rb.usc, st));
+            }
         }
         return 0;
     };
@@ -683,7 +710,8 @@ int lass_separate(lass_ctx* c, const float* mixture, const float* condition, flo
         HIP_TRY(c, lass_launch_film(condition, B, c->film_W, c->film_b, c->bn_base, c->n_shift, shift, st));
     }
     // pre_conv (resunet.py:555) is normally never materialised: encoder_block1 forms it from x0 while staging
-    if (!c->fuse_preconv) {
+    const bool fuse_pre = c->fuse_preconv && !c->wino;  // the Winograd kernels read a materialised block input
+    if (!fuse_pre) {
         ProfScope ps(c, st, P_PRECONV);
         HIP_TRY(c, lass_launch_preconv(F(pl.x0), rawp(c, "base.pre_conv.weight"), rawp(c, "base.pre_conv.bias"), B,
                                        kPreCh, (long)Tp * LASS_FCROP, F(pl.xpre), st));
@@ -707,7 +735,7 @@ int lass_separate(lass_ctx* c, const float* mixture, const float* condition, flo
         const bool fuse_pool = i < 6 && c->fuse_pool && (H % kEnc[i].dh) == 0;
         r = run_resblock(c, rb, x, rb.cin * HW, B, H, W, shift, F(pl.a2), o, o_bs, st,
                          fuse_pool ? F(pl.pool[i]) : nullptr, kEnc[i].dh,
-                         (i == 0 && c->fuse_preconv) ? F(pl.x0) : nullptr);
+                         (i == 0 && fuse_pre) ? F(pl.x0) : nullptr);
         if (r) return r;
         if (i < 6) {
             if (!fuse_pool) {

@@ -37,6 +37,8 @@ struct ConvArgs {
     int B = 0, H = 0, W = 0;
     int N = 0;  // output channels computed by this launch (GEMM rows)
     int up_h = 1;  // TCONV: vertical stride (1 or 2); horizontal stride is always 2
+    const float* w_wino = nullptr;   // Winograd-domain weights U[16][Cin][Nw] (wino.hip)
+    const float* w2_wino = nullptr;  // Winograd-domain shortcut weights [4][Cin2][Nw]
     const float* pre_w = nullptr;  // pre_conv (1x1, 1 -> 32) weight / bias for the *_PRE kinds
     const float* pre_b = nullptr;
     float* pool_out = nullptr;  // fused avg-pool of the output: (B, N, H/pool_h, W/2) dense
@@ -47,6 +49,12 @@ struct ConvArgs {
 enum ConvKind { CONV1_ACT = 0, CONV2_IDENT = 1, CONV2_SHORTCUT = 2, TCONV_ACT = 3, CONV1_ACT_PRE = 4, CONV2_IDENT_PRE = 5 };
 
 hipError_t lass_launch_conv(ConvKind kind, const ConvArgs& p, hipStream_t stream);
+
+// ---- wino.hip (Winograd F(2x2,3x3) variant of the 3x3 kinds; W must be a multiple of 32, H even) -------------------
+bool lass_wino_supported(const ConvArgs& p);
+hipError_t lass_launch_wino(ConvKind kind, const ConvArgs& p, hipStream_t stream);
+hipError_t lass_launch_wino_weights(const float* w, int Cout, int Cin, float* U, hipStream_t stream);
+hipError_t lass_launch_wino_shortcut_weights(const float* w, int Cout, int Cin, float* U, hipStream_t stream);
 
 // ---- stft.hip -----------------------------------------------------------------------------------------------------
 // tw: 1024 float2 (cos, sin)(2*pi*k/1024); win: 1024 floats (periodic Hann)

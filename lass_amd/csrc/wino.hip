@@ -1,0 +1,471 @@
+// wino.hip - Winograd F(2x2,3x3) 3x3 convolutions on the gfx950 f32 MFMA.
+//
+// Same reference semantics as conv.hip (models/resunet.py:147-165): a 3x3/stride-1/pad-1 cross-correlation, with the
+// BN+FiLM+leaky prologue, epilogue activation, residual / 1x1-shortcut(+bias) and avg-pool fusions.  Only the
+// contraction changes: every 2x2 output tile is computed from its 4x4 input patch through
+//      Y = A^T [ sum_c (G g_c G^T) .* (B^T d_c B) ] A                                   (Lavin & Gray 2016)
+// i.e. 16 independent GEMMs  M_xi[cout][tile] = sum_cin U_xi[cout][cin] * V_xi[cin][tile]  with 4 multiplies per output
+// pixel and (cin,cout) pair instead of 9: 2.25x fewer MFMA FLOPs, all of them still plain f32 FMAs.
+//
+// Mapping: v_mfma_f32_16x16x4_f32; a wave owns 32 couts x 16 Winograd tiles (one row pair of 32 pixels) and keeps all
+// 16 xi accumulators (16 xi x 2 cout-tiles x 4 regs = 128 AGPRs), so the output transform is register-local:
+// D row = (lane>>4)*4 + reg -> cout, D col = lane&15 -> tile.  Per chunk of 8 input channels a workgroup (4 waves)
+//   1. stages the activated halo tile [8][rows+2][34] (same unconditional-load staging as conv.hip),
+//   2. transforms it to V[16][8][tiles] in LDS (32 add/sub per 4x4 patch),
+//   3. stages U[16][8][NT] (weights pre-transformed once in lass_finalize),
+//   4. runs 16 xi x 2 k-steps x 2 cout-tiles MFMAs per wave.
+// The 1x1 shortcut is the same kernel family in the transform domain: a centre-only 3x3 kernel has G g G^T non-zero
+// at the four xi in {1,2}x{1,2} only, and its B^T d B there needs just the 2x2 centre of the patch.
+#include <hip/hip_runtime.h>
+#include "kernels.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int F_PRO = 1, F_PHASEB = 2, F_BIAS = 4, F_RES = 8, F_EPIACT = 16;
+constexpr int NTHREADS = 256;
+constexpr int KC = 8;
+constexpr int PWT = 16;  // Winograd tiles per row pair (32 output columns)
+
+__device__ __forceinline__ float leaky(float v) { return fmaxf(v, 0.01f * v); }
+
+// Halo-tile staging: [KC][IR][IP] raw (activated) input, walked in channel pairs (see conv.hip Phase).
+template <int IR, int IP, int HALO, int KCH, bool PRO>
+struct RawStage {
+    static constexpr int CH_ELEMS = IR * IP;
+    static constexpr int G = 2;
+    static constexpr int NGRP = KCH / G;
+    static constexpr int GRP_ELEMS = G * CH_ELEMS;
+    static constexpr int NPASS = (GRP_ELEMS + NTHREADS - 1) / NTHREADS;
+    int goff[NPASS];
+    unsigned okbits;
+    float v[NGRP][NPASS];
+
+    __device__ __forceinline__ static int upos(int tid, int k) {
+        const int u = tid + k * NTHREADS;
+        return u < GRP_ELEMS ? u : GRP_ELEMS - 1;
+    }
+    __device__ __forceinline__ void init(int tid, int y0, int x0, int H, int W) {
+        okbits = 0;
+#pragma unroll
+        for (int k = 0; k < NPASS; ++k) {
+            const int u = upos(tid, k);
+            const int cl = u >= CH_ELEMS ? 1 : 0;
+            const int w = u - cl * CH_ELEMS;
+            const int r = w / IP, x = w % IP;
+            const int gy = y0 + r - HALO, gx = x0 + x - HALO;
+            const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
+            goff[k] = cl * H * W + min(max(gy, 0), H - 1) * W + min(max(gx, 0), W - 1);
+            okbits |= (ok ? 1u : 0u) << k;
+        }
+    }
+    static constexpr int NLOADS = NGRP * NPASS;  // vector-memory loads load() issues (counted by the vmcnt waits)
+    __device__ __forceinline__ void load(const float* __restrict__ in_c0, int HW) {
+#pragma unroll
+        for (int q = 0; q < NGRP; ++q)
+#pragma unroll
+            for (int k = 0; k < NPASS; ++k) v[q][k] = in_c0[(size_t)q * G * HW + goff[k]];
+    }
+
+    // lsc / lsh: the prologue scale / shift of this chunk's channels, in LDS (staged once per workgroup)
+    __device__ __forceinline__ void store(float* lds, const float* lsc, const float* lsh, int tid) {
+#pragma unroll
+        for (int q = 0; q < NGRP; ++q)
+#pragma unroll
+            for (int k = 0; k < NPASS; ++k) {
+                const int u = upos(tid, k);
+                float t = v[q][k];
+                if (PRO) {
+                    const int c = q * G + (u >= CH_ELEMS ? 1 : 0);
+                    t = leaky(t * lsc[c] + lsh[c]);
+                }
+                t = ((okbits >> k) & 1u) ? t : 0.f;
+                lds[q * GRP_ELEMS + u] = t;
+            }
+    }
+};
+
+// Weight-slab staging by LDS-DMA (global_load_lds, 16 B per lane, no VGPRs): NXI x KC rows of NT floats from
+// Uw[xi][Cin][Nw] into lu[row][NT] (row = xi_slot*KC + c).  One wave-instruction writes 1 KiB = RPI whole rows, lane-linear;
+// the bank swizzle (16-float halves of odd rows swapped, so the two k-rows a 32-lane group reads hit disjoint banks)
+// is therefore applied on the SOURCE address and undone by the fragment reader.
+template <int NXI, int NT>
+struct UDma {
+    static constexpr int RPI = 256 / NT;                 // rows per wave-instruction
+    static constexpr int NINSTR = NXI * KC / RPI / 4;    // wave-instructions per wave
+    static_assert(NXI * KC % (RPI * 4) == 0, "rows split evenly over 4 waves");
+    __device__ __forceinline__ static void issue(const float* __restrict__ Uw, int Cin, int Nw, int c0, int n0,
+                                                 float* lu, int wave, int lane) {
+#pragma unroll
+        for (int i = 0; i < NINSTR; ++i) {
+            const int r0 = (wave * NINSTR + i) * RPI;
+            const int r = r0 + lane / (NT / 4);
+            const int colpos = (lane % (NT / 4)) * 4;
+            const int xi = r / KC, c = r % KC;
+            const float* g = Uw + ((size_t)xi * Cin + c0 + c) * Nw + n0 + (colpos ^ ((r & 1) << 4));
+            // Issued from inline asm so that hipcc does not know about the pending LDS write: with the builtin it
+            // drains vmcnt(0) in front of the next ds_read (the transform), exposing the DMA and the raw prefetch.
+            // Completion is tracked by hand (wait_vmcnt below); M0 = wave-uniform LDS byte address of this 1-KiB piece.
+            const unsigned lds_addr = __builtin_amdgcn_readfirstlane(
+                (unsigned)(size_t)(__attribute__((address_space(3))) float*)(lu + r0 * NT));
+            unsigned keep;
+            asm volatile(
+                "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                : "=&s"(keep)
+                : "v"(g), "s"(lds_addr)
+                : "memory");
+        }
+    }
+};
+
+__device__ __forceinline__ void lds_barrier() {  // workgroup barrier that does NOT drain vmcnt (LDS-DMA stays in flight)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {  // all but the N youngest vector-memory operations are complete
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// S k-steps of 2 MFMAs; LDS row of step s = s*4 (+ lane>>4): rows are [xi-slot][channel] with KC/4 steps per slot.
+// The three fragment reads of step s+PFD are issued before the MFMAs of step s (pinned: hipcc sinks them otherwise and
+// then waits lgkmcnt(0) in front of every MFMA pair).
+template <int S, int UPITCH, int VPITCH, typename XiOf>
+__device__ __forceinline__ void gemm_steps(const float* afrag0, const float* afrag1, const float* bfrag,
+                                           f32x4 (&acc)[16][2], XiOf xi_of) {
+    constexpr int PFD = 3;
+    float bv[PFD + 1], a0[PFD + 1], a1[PFD + 1];
+    auto rd = [&](int s) {
+        bv[s % (PFD + 1)] = bfrag[(s * 4) * VPITCH];
+        a0[s % (PFD + 1)] = afrag0[(s * 4) * UPITCH];
+        a1[s % (PFD + 1)] = afrag1[(s * 4) * UPITCH];
+    };
+#pragma unroll
+    for (int s = 0; s < PFD && s < S; ++s) rd(s);
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        if (s + PFD < S) rd(s + PFD);
+        __builtin_amdgcn_sched_barrier(0);
+        const int xi = xi_of(s);
+        acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s % (PFD + 1)], bv[s % (PFD + 1)], acc[xi][0], 0, 0, 0);
+        acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s % (PFD + 1)], bv[s % (PFD + 1)], acc[xi][1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// WCO x WWT waves (product 4): block = 32*WCO couts x 16*WWT Winograd tiles = (2*WWT output rows) x 32 output cols.
+template <int WCO, int WWT, int FLAGS>
+__global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
+    static_assert(WCO * WWT == 4, "4 waves");
+    constexpr bool PRO = (FLAGS & F_PRO) != 0;
+    constexpr bool HASB = (FLAGS & F_PHASEB) != 0;
+    constexpr bool EPI = (FLAGS & F_EPIACT) != 0;
+    constexpr bool BIAS = (FLAGS & F_BIAS) != 0;
+    constexpr bool RES = (FLAGS & F_RES) != 0;
+    constexpr int NT = 32 * WCO;
+    constexpr int NWT = 16 * WWT;
+    constexpr int OR_ = 2 * WWT, OC = 2 * PWT;  // output rows / cols of the block
+    constexpr int IR = OR_ + 2, IP = OC + 2;
+    constexpr int VP = NWT + 16;  // V row pitch (floats): spreads the 4 k-rows of a fragment read over the banks
+    using RA = RawStage<IR, IP, 1, KC, PRO>;
+    using RB = RawStage<OR_, OC, 0, KC, false>;
+    using UA = UDma<16, NT>;
+    using UB = UDma<4, NT>;
+    constexpr int RAW_F = KC * IR * IP;
+    constexpr int V_F = 16 * KC * VP;
+    constexpr int U_F = 16 * KC * NT;
+    constexpr int MAXC = 768;  // largest Cin of a 3x3 conv in the network (decoder_block1/2.conv1)
+    constexpr int NTAB = (EPI ? 2 * NT : 0) + (BIAS ? NT : 0) + (PRO ? 2 * MAXC : 0);
+    static_assert(RAW_F % 4 == 0 && V_F % 4 == 0, "16-B alignment of the LDS regions");
+
+    __shared__ __attribute__((aligned(16))) float lds[RAW_F + V_F + U_F + NTAB];
+    float* lraw = lds;
+    float* lv = lds + RAW_F;
+    float* lu = lv + V_F;
+    float* lds_es = lu + U_F;
+    float* lds_eh = lds_es + NT;
+    float* lds_bias = lu + U_F + (EPI ? 2 * NT : 0);
+    float* lds_sc = lu + U_F + (EPI ? 2 * NT : 0) + (BIAS ? NT : 0);  // PRO: scale / shift of every input channel
+    float* lds_sh = lds_sc + MAXC;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wco = wave / WWT, wwt = wave % WWT;
+    const int b = blockIdx.z;
+    const int n0 = blockIdx.y * NT;
+    const int tiles_x = p.W / OC;
+    const int y0 = (blockIdx.x / tiles_x) * OR_, x0 = (blockIdx.x % tiles_x) * OC;
+    const int HW = p.H * p.W;
+    const float* in_b = p.in + (size_t)b * p.in_bs;
+    const float* sc = PRO ? p.pro_scale : nullptr;
+    const float* sh = PRO ? p.pro_shift + (size_t)b * p.pro_shift_bs : nullptr;
+
+    if (EPI && tid < NT) {
+        lds_es[tid] = p.epi_scale[n0 + tid];
+        lds_eh[tid] = p.epi_shift[(size_t)b * p.epi_shift_bs + n0 + tid];
+    }
+    if (BIAS && tid < NT) lds_bias[tid] = p.bias[n0 + tid];
+    if (PRO) {
+        for (int c = tid; c < p.Cin; c += NTHREADS) {
+            lds_sc[c] = sc[c];
+            lds_sh[c] = sh[c];
+        }
+    }
+
+    f32x4 acc[16][2];
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[xi][t][r] = 0.f;
+
+    const int kq = lane >> 4, l15 = lane & 15;
+    const float* bfrag = lv + kq * VP + wwt * 16 + l15;
+    const int sw = (kq & 1) * 16;  // undo the LDS-DMA source swizzle: odd rows hold their 16-float halves swapped
+    const float* afrag0 = lu + kq * NT + wco * 32 + sw + l15;         // cout tile 0
+    const float* afrag1 = lu + kq * NT + wco * 32 + (16 - sw) + l15;  // cout tile 1
+
+    // ---- main phase: 3x3 over p.in ------------------------------------------------------------------------------
+    // Per chunk:  barrier | raw(ch) regs->LDS | issue U(ch) LDS-DMA | issue raw(ch+1) loads | barrier |
+    //             transform raw->V | wait U(ch) (counted vmcnt: the raw(ch+1) loads stay in flight) | barrier | MFMAs
+    {
+        RA ra;
+        ra.init(tid, y0, x0, p.H, p.W);
+        ra.load(in_b, HW);
+        const int nch = p.Cin / KC;
+        for (int ch = 0; ch < nch; ++ch) {
+            const bool more = ch + 1 < nch;
+            lds_barrier();  // previous chunk's MFMAs have finished reading V / U (first pass: tables visible)
+            ra.store(lraw, lds_sc + ch * KC, lds_sh + ch * KC, tid);
+            __builtin_amdgcn_sched_barrier(0);
+            UA::issue(p.w_wino, p.Cin, p.Nw, ch * KC, n0, lu, wave, lane);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) ra.load(in_b + (size_t)(ch + 1) * KC * HW, HW);
+            __builtin_amdgcn_sched_barrier(0);
+            lds_barrier();  // raw tile visible
+            // input transform V = B^T d B: one (channel, tile) item per thread and pass
+#pragma unroll
+            for (int it = 0; it < (KC * NWT) / NTHREADS; ++it) {
+                const int item = tid + it * NTHREADS;
+                const int c = item / NWT, wt = item % NWT;
+                const int wty = wt / PWT, wtx = wt % PWT;
+                const float* src = lraw + c * (IR * IP) + (2 * wty) * IP + 2 * wtx;
+                float d[4][4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float2 lo = *reinterpret_cast<const float2*>(src + i * IP);
+                    const float2 hi = *reinterpret_cast<const float2*>(src + i * IP + 2);
+                    d[i][0] = lo.x; d[i][1] = lo.y; d[i][2] = hi.x; d[i][3] = hi.y;
+                }
+                float tt[4][4];
+#pragma unroll
+                for (int jx = 0; jx < 4; ++jx) {
+                    tt[0][jx] = d[0][jx] - d[2][jx];
+                    tt[1][jx] = d[1][jx] + d[2][jx];
+                    tt[2][jx] = d[2][jx] - d[1][jx];
+                    tt[3][jx] = d[1][jx] - d[3][jx];
+                }
+                float* dst = lv + c * VP + wt;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    dst[(4 * i + 0) * (KC * VP)] = tt[i][0] - tt[i][2];
+                    dst[(4 * i + 1) * (KC * VP)] = tt[i][1] + tt[i][2];
+                    dst[(4 * i + 2) * (KC * VP)] = tt[i][2] - tt[i][1];
+                    dst[(4 * i + 3) * (KC * VP)] = tt[i][1] - tt[i][3];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (more)
+                wait_vmcnt<RA::NLOADS>();  // this wave's U(ch) rows have landed; raw(ch+1) may still be in flight
+            else
+                wait_vmcnt<0>();
+            lds_barrier();  // V visible, every wave's U rows landed
+            // 16 GEMMs: M_xi += U_xi (32 couts x 8 cin) * V_xi (8 cin x 16 tiles)
+            gemm_steps<16 * (KC / 4), NT, VP>(afrag0, afrag1, bfrag, acc, [](int s) { return s / (KC / 4); });
+        }
+    }
+    // ---- shortcut phase: 1x1 over p.in2, in the transform domain (xi in {5,6,9,10}) -------------------------------
+    if (HASB) {
+        RB rb;
+        const float* in2_b = p.in2 + (size_t)b * p.in2_bs;
+        rb.init(tid, y0, x0, p.H, p.W);
+        rb.load(in2_b, HW);
+        const int nch = p.Cin2 / KC;
+        for (int ch = 0; ch < nch; ++ch) {
+            const bool more = ch + 1 < nch;
+            lds_barrier();
+            rb.store(lraw, nullptr, nullptr, tid);
+            __builtin_amdgcn_sched_barrier(0);
+            UB::issue(p.w2_wino, p.Cin2, p.Nw, ch * KC, n0, lu, wave, lane);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) rb.load(in2_b + (size_t)(ch + 1) * KC * HW, HW);
+            __builtin_amdgcn_sched_barrier(0);
+            lds_barrier();
+#pragma unroll
+            for (int it = 0; it < (KC * NWT) / NTHREADS; ++it) {
+                const int item = tid + it * NTHREADS;
+                const int c = item / NWT, wt = item % NWT;
+                const int wty = wt / PWT, wtx = wt % PWT;
+                const float* src = lraw + c * (OR_ * OC) + (2 * wty) * OC + 2 * wtx;
+                const float2 r1 = *reinterpret_cast<const float2*>(src);       // patch rows 1,2 x cols 1,2
+                const float2 r2 = *reinterpret_cast<const float2*>(src + OC);
+                const float t1a = r1.x + r2.x, t1b = r1.y + r2.y;  // tt[1][1], tt[1][2]
+                const float t2a = r2.x - r1.x, t2b = r2.y - r1.y;  // tt[2][1], tt[2][2]
+                float* dst = lv + c * VP + wt;
+                dst[0 * (KC * VP)] = t1a + t1b;  // V[1][1]
+                dst[1 * (KC * VP)] = t1b - t1a;  // V[1][2]
+                dst[2 * (KC * VP)] = t2a + t2b;  // V[2][1]
+                dst[3 * (KC * VP)] = t2b - t2a;  // V[2][2]
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (more)
+                wait_vmcnt<RB::NLOADS>();
+            else
+                wait_vmcnt<0>();
+            lds_barrier();
+            gemm_steps<4 * (KC / 4), NT, VP>(afrag0, afrag1, bfrag, acc, [](int s) {
+                const int q = s / (KC / 4);
+                return (q >> 1) * 4 + (q & 1) + 5;  // 5, 6, 9, 10
+            });
+        }
+    }
+
+    // ---- output transform Y = A^T M A and epilogue -----------------------------------------------------------------
+    const int wty = wwt, wtx = l15;  // this lane's tile: row pair wwt of the block, column pair l15
+    const int oy = y0 + 2 * wty, ox = x0 + 2 * wtx;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int nl = wco * 32 + t * 16 + kq * 4 + r;  // channel within the block
+            const int n = n0 + nl;
+            float s[2][4];
+#pragma unroll
+            for (int jx = 0; jx < 4; ++jx) {
+                s[0][jx] = acc[0 + jx][t][r] + acc[4 + jx][t][r] + acc[8 + jx][t][r];
+                s[1][jx] = acc[4 + jx][t][r] - acc[8 + jx][t][r] - acc[12 + jx][t][r];
+            }
+            float y[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                y[i][0] = s[i][0] + s[i][1] + s[i][2];
+                y[i][1] = s[i][1] - s[i][2] - s[i][3];
+            }
+            const size_t pix = (size_t)n * HW + (size_t)oy * p.W + ox;
+            if (BIAS) {
+                const float bb = lds_bias[nl];
+                y[0][0] += bb; y[0][1] += bb; y[1][0] += bb; y[1][1] += bb;
+            }
+            if (RES) {
+                const float* rp = p.res + (size_t)b * p.res_bs + (size_t)n * HW + (size_t)min(oy, p.H - 1) * p.W + ox;
+                const float2 r0 = *reinterpret_cast<const float2*>(rp);
+                const float2 r1 = *reinterpret_cast<const float2*>(rp + (oy + 1 < p.H ? p.W : 0));
+                y[0][0] += r0.x; y[0][1] += r0.y; y[1][0] += r1.x; y[1][1] += r1.y;
+            }
+            if (EPI) {
+                const float es = lds_es[nl], eh = lds_eh[nl];
+                y[0][0] = leaky(y[0][0] * es + eh); y[0][1] = leaky(y[0][1] * es + eh);
+                y[1][0] = leaky(y[1][0] * es + eh); y[1][1] = leaky(y[1][1] * es + eh);
+            }
+            float* dst = p.out + (size_t)b * p.out_bs + pix;
+            if (oy < p.H) *reinterpret_cast<float2*>(dst) = make_float2(y[0][0], y[0][1]);
+            if (oy + 1 < p.H) *reinterpret_cast<float2*>(dst + p.W) = make_float2(y[1][0], y[1][1]);
+            if (p.pool_out) {
+                const int Wo = p.W / 2;
+                if (p.pool_h == 2) {
+                    float sum = y[0][0] + y[0][1];  // reference summation order (row-major)
+                    sum += y[1][0];
+                    sum += y[1][1];
+                    if (oy + 1 < p.H)
+                        p.pool_out[((size_t)b * p.N + n) * (p.H / 2) * Wo + (size_t)(oy >> 1) * Wo + (ox >> 1)] =
+                            sum * 0.25f;
+                } else {
+                    float* pd = p.pool_out + ((size_t)b * p.N + n) * p.H * Wo + (size_t)oy * Wo + (ox >> 1);
+                    if (oy < p.H) pd[0] = (y[0][0] + y[0][1]) * 0.5f;
+                    if (oy + 1 < p.H) pd[Wo] = (y[1][0] + y[1][1]) * 0.5f;
+                }
+            }
+        }
+    }
+}
+
+// U[xi][cin][cout] = (G g G^T)[xi] for g = w[cout][cin][3][3];  G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+__global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restrict__ w, int Cout, int Cin,
+                                                           float* __restrict__ U) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;  // (cin, cout), cout fastest
+    if (i >= (long)Cout * Cin) return;
+    const int co = (int)(i % Cout), ci = (int)(i / Cout);
+    const float* g = w + ((size_t)co * Cin + ci) * 9;
+    double gg[3][3];
+    for (int a = 0; a < 3; ++a)
+        for (int c = 0; c < 3; ++c) gg[a][c] = g[a * 3 + c];
+    const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    double t[4][3];
+    for (int a = 0; a < 4; ++a)
+        for (int c = 0; c < 3; ++c) t[a][c] = G[a][0] * gg[0][c] + G[a][1] * gg[1][c] + G[a][2] * gg[2][c];
+    for (int a = 0; a < 4; ++a)
+        for (int c = 0; c < 4; ++c) {
+            const double u = t[a][0] * G[c][0] + t[a][1] * G[c][1] + t[a][2] * G[c][2];
+            U[((size_t)(a * 4 + c) * Cin + ci) * Cout + co] = (float)u;
+        }
+}
+
+// Shortcut (1x1) weights in the transform domain: q = (i-1)*2 + (j-1), i,j in {1,2}: G[i][1]*w*G[j][1] = +-w/4
+__global__ __launch_bounds__(256) void wino_shortcut_weights_kernel(const float* __restrict__ w, int Cout, int Cin,
+                                                                    float* __restrict__ U) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)Cout * Cin) return;
+    const int co = (int)(i % Cout), ci = (int)(i / Cout);
+    const float v = w[(size_t)co * Cin + ci] * 0.25f;
+    const float sgn[4] = {1.f, -1.f, -1.f, 1.f};
+    for (int q = 0; q < 4; ++q) U[((size_t)q * Cin + ci) * Cout + co] = sgn[q] * v;
+}
+
+template <int FLAGS>
+hipError_t launch_wino(const ConvArgs& p, hipStream_t stream) {
+    if (p.N % 64 == 0) {
+        dim3 grid((p.W / 32) * ((p.H + 3) / 4), p.N / 64, p.B);
+        hipLaunchKernelGGL((wino_kernel<2, 2, FLAGS>), grid, dim3(NTHREADS), 0, stream, p);
+    } else {
+        dim3 grid((p.W / 32) * ((p.H + 7) / 8), p.N / 32, p.B);
+        hipLaunchKernelGGL((wino_kernel<1, 4, FLAGS>), grid, dim3(NTHREADS), 0, stream, p);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace
+
+bool lass_wino_supported(const ConvArgs& p) {
+    return p.W >= 32 && (p.W % 32) == 0 && (p.H % 2) == 0 && p.Cin % KC == 0 && p.N % 32 == 0 && (p.Nw % 4) == 0;
+}
+
+hipError_t lass_launch_wino(ConvKind kind, const ConvArgs& p, hipStream_t stream) {
+    if (!lass_wino_supported(p) || !p.w_wino || !p.in || !p.out) return hipErrorInvalidValue;
+    switch (kind) {
+        case CONV1_ACT:
+            if (!p.pro_scale || !p.pro_shift || !p.epi_scale || !p.epi_shift) return hipErrorInvalidValue;
+            return launch_wino<F_PRO | F_EPIACT>(p, stream);
+        case CONV2_IDENT:
+            if (!p.res) return hipErrorInvalidValue;
+            return launch_wino<F_RES>(p, stream);
+        case CONV2_SHORTCUT:
+            if (!p.in2 || !p.w2_wino || !p.bias || p.Cin2 % KC != 0) return hipErrorInvalidValue;
+            return launch_wino<F_PHASEB | F_BIAS>(p, stream);
+        default:
+            return hipErrorInvalidValue;
+    }
+}
+
+hipError_t lass_launch_wino_weights(const float* w, int Cout, int Cin, float* U, hipStream_t stream) {
+    const long n = (long)Cout * Cin;
+    hipLaunchKernelGGL(wino_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, w, Cout, Cin, U);
+    return hipGetLastError();
+}
+
+hipError_t lass_launch_wino_shortcut_weights(const float* w, int Cout, int Cin, float* U, hipStream_t stream) {
+    const long n = (long)Cout * Cin;
+    hipLaunchKernelGGL(wino_shortcut_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, w, Cout,
+                       Cin, U);
+    return hipGetLastError();
+}
