@@ -17,6 +17,9 @@
 // The 1x1 shortcut is the same kernel family in the transform domain: a centre-only 3x3 kernel has G g G^T non-zero
 // at the four xi in {1,2}x{1,2} only, and its B^T d B there needs just the 2x2 centre of the patch.
 #include <hip/hip_runtime.h>
+#include <cstdio>
+#include <type_traits>
+#include <vector>
 #include "kernels.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -40,7 +43,7 @@ struct RawStage {
     static constexpr int NPASS = (GRP_ELEMS + NTHREADS - 1) / NTHREADS;
     int goff[NPASS];
     unsigned okbits;
-    float v[NGRP][NPASS];
+    float v[2][NGRP][NPASS];  // two chunks in flight: chunk c+2 is requested while chunk c is contracted
 
     __device__ __forceinline__ static int upos(int tid, int k) {
         const int u = tid + k * NTHREADS;
@@ -61,24 +64,36 @@ struct RawStage {
         }
     }
     static constexpr int NLOADS = NGRP * NPASS;  // vector-memory loads load() issues (counted by the vmcnt waits)
+    template <int BUF>
     __device__ __forceinline__ void load(const float* __restrict__ in_c0, int HW) {
 #pragma unroll
         for (int q = 0; q < NGRP; ++q)
 #pragma unroll
-            for (int k = 0; k < NPASS; ++k) v[q][k] = in_c0[(size_t)q * G * HW + goff[k]];
+            for (int k = 0; k < NPASS; ++k) v[BUF][q][k] = in_c0[(size_t)q * G * HW + goff[k]];
     }
-
-    // lsc / lsh: the prologue scale / shift of this chunk's channels, in LDS (staged once per workgroup)
+    // lsc / lsh: the prologue scale / shift of this chunk's channels in LDS (staged once per workgroup); all table reads
+    // are issued up front (uniform b128 reads) so the element loop below has no LDS read behind an LDS write.
+    template <int BUF>
     __device__ __forceinline__ void store(float* lds, const float* lsc, const float* lsh, int tid) {
+        float tsc[KCH], tsh[KCH];
+        if (PRO) {
+#pragma unroll
+            for (int c = 0; c < KCH; c += 4) {
+                const float4 a = *reinterpret_cast<const float4*>(lsc + c);
+                const float4 b = *reinterpret_cast<const float4*>(lsh + c);
+                tsc[c] = a.x; tsc[c + 1] = a.y; tsc[c + 2] = a.z; tsc[c + 3] = a.w;
+                tsh[c] = b.x; tsh[c + 1] = b.y; tsh[c + 2] = b.z; tsh[c + 3] = b.w;
+            }
+        }
 #pragma unroll
         for (int q = 0; q < NGRP; ++q)
 #pragma unroll
             for (int k = 0; k < NPASS; ++k) {
                 const int u = upos(tid, k);
-                float t = v[q][k];
+                float t = v[BUF][q][k];
                 if (PRO) {
-                    const int c = q * G + (u >= CH_ELEMS ? 1 : 0);
-                    t = leaky(t * lsc[c] + lsh[c]);
+                    const bool hi = u >= CH_ELEMS;
+                    t = leaky(t * (hi ? tsc[q * G + 1] : tsc[q * G]) + (hi ? tsh[q * G + 1] : tsh[q * G]));
                 }
                 t = ((okbits >> k) & 1u) ? t : 0.f;
                 lds[q * GRP_ELEMS + u] = t;
@@ -92,23 +107,27 @@ struct RawStage {
 // is therefore applied on the SOURCE address and undone by the fragment reader.
 template <int NXI, int NT>
 struct UDma {
-    static constexpr int RPI = 256 / NT;                 // rows per wave-instruction
+    static constexpr int RPI = 256 / NT;                 // rows per wave-instruction (4 or 8: never straddles a xi slot)
     static constexpr int NINSTR = NXI * KC / RPI / 4;    // wave-instructions per wave
-    static_assert(NXI * KC % (RPI * 4) == 0, "rows split evenly over 4 waves");
-    __device__ __forceinline__ static void issue(const float* __restrict__ Uw, int Cin, int Nw, int c0, int n0,
-                                                 float* lu, int wave, int lane) {
+    static_assert(NXI * KC % (RPI * 4) == 0 && KC % RPI == 0, "rows split evenly; an instruction stays in one xi slot");
+    // Per-lane part of the source address (constant over chunks and instructions): row-in-instruction * Nw + swizzled col
+    __device__ __forceinline__ static const float* lane_base(const float* Uw, int Nw, int n0, int lane) {
+        const int rl = lane / (NT / 4);                  // row within the instruction's RPI rows
+        const int colpos = (lane % (NT / 4)) * 4;
+        return Uw + (size_t)rl * Nw + n0 + (colpos ^ ((rl & 1) << 4));  // r0 is even, so (r & 1) == (rl & 1)
+    }
+    // lds_base: LDS byte address of lu (uniform).  c0: first channel of the chunk.
+    __device__ __forceinline__ static void issue(const float* lane_ptr, int Cin, int Nw, int c0, unsigned lds_base,
+                                                 int wave) {
 #pragma unroll
         for (int i = 0; i < NINSTR; ++i) {
-            const int r0 = (wave * NINSTR + i) * RPI;
-            const int r = r0 + lane / (NT / 4);
-            const int colpos = (lane % (NT / 4)) * 4;
-            const int xi = r / KC, c = r % KC;
-            const float* g = Uw + ((size_t)xi * Cin + c0 + c) * Nw + n0 + (colpos ^ ((r & 1) << 4));
+            const int r0 = (wave * NINSTR + i) * RPI;    // wave-uniform
+            const int xi = r0 / KC, c = r0 % KC;
+            const float* g = lane_ptr + ((size_t)xi * Cin + c0 + c) * Nw;
             // Issued from inline asm so that hipcc does not know about the pending LDS write: with the builtin it
             // drains vmcnt(0) in front of the next ds_read (the transform), exposing the DMA and the raw prefetch.
-            // Completion is tracked by hand (wait_vmcnt below); M0 = wave-uniform LDS byte address of this 1-KiB piece.
-            const unsigned lds_addr = __builtin_amdgcn_readfirstlane(
-                (unsigned)(size_t)(__attribute__((address_space(3))) float*)(lu + r0 * NT));
+            // Completion is tracked by hand (wait_vmcnt); M0 = wave-uniform LDS byte address of this 1-KiB piece.
+            const unsigned lds_addr = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(r0 * NT * 4));
             unsigned keep;
             asm volatile(
                 "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
@@ -212,6 +231,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
         }
     }
 
+#ifdef LASS_CONV_DIAG
+    const long long k_c0 = clock64(), k_r0 = wall_clock64();
+    long long dg[6] = {0, 0, 0, 0, 0, 0};
+#endif
     f32x4 acc[16][2];
 #pragma unroll
     for (int xi = 0; xi < 16; ++xi)
@@ -227,23 +250,41 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
     const float* afrag1 = lu + kq * NT + wco * 32 + (16 - sw) + l15;  // cout tile 1
 
     // ---- main phase: 3x3 over p.in ------------------------------------------------------------------------------
-    // Per chunk:  barrier | raw(ch) regs->LDS | issue U(ch) LDS-DMA | issue raw(ch+1) loads | barrier |
-    //             transform raw->V | wait U(ch) (counted vmcnt: the raw(ch+1) loads stay in flight) | barrier | MFMAs
+    // Per chunk:  barrier | raw(ch) regs->LDS | issue U(ch) LDS-DMA | issue raw(ch+2) loads | barrier |
+    //             transform raw->V | wait U(ch) (counted vmcnt: the raw(ch+2) loads stay in flight) | barrier |
+    //             MFMAs
+    const unsigned lu_addr = (unsigned)(size_t)(__attribute__((address_space(3))) float*)lu;
     {
         RA ra;
         ra.init(tid, y0, x0, p.H, p.W);
-        ra.load(in_b, HW);
-        const int nch = p.Cin / KC;
-        for (int ch = 0; ch < nch; ++ch) {
-            const bool more = ch + 1 < nch;
-            lds_barrier();  // previous chunk's MFMAs have finished reading V / U (first pass: tables visible)
-            ra.store(lraw, lds_sc + ch * KC, lds_sh + ch * KC, tid);
+        const int nch = p.Cin / KC;  // even (host-checked)
+        ra.template load<0>(in_b, HW);
+        ra.template load<1>(in_b + (size_t)KC * HW, HW);
+        const float* ulane = UA::lane_base(p.w_wino, p.Nw, n0, lane);
+        lds_barrier();  // prologue tables visible
+        auto chunk = [&](int ch, auto buf) {
+            constexpr int BUF = decltype(buf)::value;
+#ifdef LASS_CONV_DIAG
+            const long long t0 = clock64();
+#endif
+            lds_barrier();  // previous chunk's MFMAs have finished reading V / U
+#ifdef LASS_CONV_DIAG
+            const long long t1 = clock64();
+#endif
+            ra.template store<BUF>(lraw, lds_sc + ch * KC, lds_sh + ch * KC, tid);
             __builtin_amdgcn_sched_barrier(0);
-            UA::issue(p.w_wino, p.Cin, p.Nw, ch * KC, n0, lu, wave, lane);
+            UA::issue(ulane, p.Cin, p.Nw, ch * KC, lu_addr, wave);
             __builtin_amdgcn_sched_barrier(0);
-            if (more) ra.load(in_b + (size_t)(ch + 1) * KC * HW, HW);
+            const bool pf = ch + 2 < nch;
+            if (pf) ra.template load<BUF>(in_b + (size_t)(ch + 2) * KC * HW, HW);
             __builtin_amdgcn_sched_barrier(0);
+#ifdef LASS_CONV_DIAG
+            const long long t2 = clock64();
+#endif
             lds_barrier();  // raw tile visible
+#ifdef LASS_CONV_DIAG
+            const long long t3 = clock64();
+#endif
             // input transform V = B^T d B: one (channel, tile) item per thread and pass
 #pragma unroll
             for (int it = 0; it < (KC * NWT) / NTHREADS; ++it) {
@@ -276,13 +317,27 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (more)
-                wait_vmcnt<RA::NLOADS>();  // this wave's U(ch) rows have landed; raw(ch+1) may still be in flight
+#ifdef LASS_CONV_DIAG
+            const long long t4 = clock64();
+#endif
+            if (pf)
+                wait_vmcnt<RA::NLOADS>();  // this wave's U(ch) rows have landed; raw(ch+2) may still be in flight
             else
                 wait_vmcnt<0>();
             lds_barrier();  // V visible, every wave's U rows landed
+#ifdef LASS_CONV_DIAG
+            const long long t5 = clock64();
+#endif
             // 16 GEMMs: M_xi += U_xi (32 couts x 8 cin) * V_xi (8 cin x 16 tiles)
             gemm_steps<16 * (KC / 4), NT, VP>(afrag0, afrag1, bfrag, acc, [](int s) { return s / (KC / 4); });
+#ifdef LASS_CONV_DIAG
+            dg[0] += t1 - t0; dg[1] += t2 - t1; dg[2] += t3 - t2; dg[3] += t4 - t3; dg[4] += t5 - t4;
+            dg[5] += clock64() - t5;
+#endif
+        };
+        for (int ch = 0; ch < nch; ch += 2) {
+            chunk(ch, std::integral_constant<int, 0>{});
+            chunk(ch + 1, std::integral_constant<int, 1>{});
         }
     }
     // ---- shortcut phase: 1x1 over p.in2, in the transform domain (xi in {5,6,9,10}) -------------------------------
@@ -290,16 +345,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
         RB rb;
         const float* in2_b = p.in2 + (size_t)b * p.in2_bs;
         rb.init(tid, y0, x0, p.H, p.W);
-        rb.load(in2_b, HW);
-        const int nch = p.Cin2 / KC;
-        for (int ch = 0; ch < nch; ++ch) {
-            const bool more = ch + 1 < nch;
+        const int nch = p.Cin2 / KC;  // even (host-checked)
+        rb.template load<0>(in2_b, HW);
+        rb.template load<1>(in2_b + (size_t)KC * HW, HW);
+        const float* ulane = UB::lane_base(p.w2_wino, p.Nw, n0, lane);
+        auto chunk = [&](int ch, auto buf) {
+            constexpr int BUF = decltype(buf)::value;
             lds_barrier();
-            rb.store(lraw, nullptr, nullptr, tid);
+            rb.template store<BUF>(lraw, nullptr, nullptr, tid);
             __builtin_amdgcn_sched_barrier(0);
-            UB::issue(p.w2_wino, p.Cin2, p.Nw, ch * KC, n0, lu, wave, lane);
+            UB::issue(ulane, p.Cin2, p.Nw, ch * KC, lu_addr, wave);
             __builtin_amdgcn_sched_barrier(0);
-            if (more) rb.load(in2_b + (size_t)(ch + 1) * KC * HW, HW);
+            const bool pf = ch + 2 < nch;
+            if (pf) rb.template load<BUF>(in2_b + (size_t)(ch + 2) * KC * HW, HW);
             __builtin_amdgcn_sched_barrier(0);
             lds_barrier();
 #pragma unroll
@@ -319,7 +377,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
                 dst[3 * (KC * VP)] = t2b - t2a;  // V[2][2]
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (more)
+            if (pf)
                 wait_vmcnt<RB::NLOADS>();
             else
                 wait_vmcnt<0>();
@@ -328,6 +386,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
                 const int q = s / (KC / 4);
                 return (q >> 1) * 4 + (q & 1) + 5;  // 5, 6, 9, 10
             });
+        };
+        for (int ch = 0; ch < nch; ch += 2) {
+            chunk(ch, std::integral_constant<int, 0>{});
+            chunk(ch + 1, std::integral_constant<int, 1>{});
         }
     }
 
@@ -388,6 +450,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
             }
         }
     }
+#ifdef LASS_CONV_DIAG
+    if (p.dbg && tid == 0) {
+        long long* d = p.dbg + 8 * ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+        for (int i = 0; i < 6; ++i) d[i] = dg[i];
+        d[6] = clock64() - k_c0;
+        d[7] = wall_clock64() - k_r0;
+    }
+#endif
 }
 
 // U[xi][cin][cout] = (G g G^T)[xi] for g = w[cout][cin][3][3];  G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
@@ -423,21 +493,49 @@ __global__ __launch_bounds__(256) void wino_shortcut_weights_kernel(const float*
 }
 
 template <int FLAGS>
-hipError_t launch_wino(const ConvArgs& p, hipStream_t stream) {
-    if (p.N % 64 == 0) {
-        dim3 grid((p.W / 32) * ((p.H + 3) / 4), p.N / 64, p.B);
-        hipLaunchKernelGGL((wino_kernel<2, 2, FLAGS>), grid, dim3(NTHREADS), 0, stream, p);
-    } else {
-        dim3 grid((p.W / 32) * ((p.H + 7) / 8), p.N / 32, p.B);
-        hipLaunchKernelGGL((wino_kernel<1, 4, FLAGS>), grid, dim3(NTHREADS), 0, stream, p);
+hipError_t launch_wino(const ConvArgs& p0, hipStream_t stream) {
+    ConvArgs p = p0;
+    const bool wide = p.N % 64 == 0;
+    dim3 grid = wide ? dim3((p.W / 32) * ((p.H + 3) / 4), p.N / 64, p.B) : dim3((p.W / 32) * ((p.H + 7) / 8), p.N / 32, p.B);
+#ifdef LASS_CONV_DIAG
+    static long long* dbuf = nullptr;
+    static size_t dcap = 0;
+    const size_t nblk = (size_t)grid.x * grid.y * grid.z;
+    if (nblk > dcap) {
+        if (dbuf) (void)hipFree(dbuf);
+        (void)hipMalloc((void**)&dbuf, nblk * 64);
+        dcap = nblk;
     }
+    p.dbg = dbuf;
+#endif
+    if (wide)
+        hipLaunchKernelGGL((wino_kernel<2, 2, FLAGS>), grid, dim3(NTHREADS), 0, stream, p);
+    else
+        hipLaunchKernelGGL((wino_kernel<1, 4, FLAGS>), grid, dim3(NTHREADS), 0, stream, p);
+#ifdef LASS_CONV_DIAG
+    {
+        std::vector<long long> h(nblk * 8);
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpy(h.data(), dbuf, nblk * 64, hipMemcpyDeviceToHost);
+        double s[8] = {0};
+        for (size_t i = 0; i < nblk; ++i)
+            for (int k = 0; k < 8; ++k) s[k] += (double)h[i * 8 + k];
+        const double nch = p.Cin / 8.0;
+        for (double& v : s) v /= (double)nblk;
+        fprintf(stderr,
+                "[wino-diag] Cin=%d N=%d %dx%d blocks=%zu | per chunk: barA %.0f  store+issue %.0f  barB %.0f  transform %.0f  "
+                "waitU+barC %.0f  mfma %.0f | block total %.0f cycles, clock %.3f GHz\n",
+                p.Cin, p.N, p.H, p.W, nblk, s[0] / nch, s[1] / nch, s[2] / nch, s[3] / nch, s[4] / nch, s[5] / nch, s[6],
+                s[6] / s[7] * 0.1);
+    }
+#endif
     return hipGetLastError();
 }
 
 }  // namespace
 
 bool lass_wino_supported(const ConvArgs& p) {
-    return p.W >= 32 && (p.W % 32) == 0 && (p.H % 2) == 0 && p.Cin % KC == 0 && p.N % 32 == 0 && (p.Nw % 4) == 0;
+    return p.W >= 32 && (p.W % 32) == 0 && (p.H % 2) == 0 && p.Cin % (2 * KC) == 0 && p.N % 32 == 0 && (p.Nw % 4) == 0;
 }
 
 hipError_t lass_launch_wino(ConvKind kind, const ConvArgs& p, hipStream_t stream) {
@@ -450,7 +548,7 @@ hipError_t lass_launch_wino(ConvKind kind, const ConvArgs& p, hipStream_t stream
             if (!p.res) return hipErrorInvalidValue;
             return launch_wino<F_RES>(p, stream);
         case CONV2_SHORTCUT:
-            if (!p.in2 || !p.w2_wino || !p.bias || p.Cin2 % KC != 0) return hipErrorInvalidValue;
+            if (!p.in2 || !p.w2_wino || !p.bias || p.Cin2 % (2 * KC) != 0) return hipErrorInvalidValue;
             return launch_wino<F_PHASEB | F_BIAS>(p, stream);
         default:
             return hipErrorInvalidValue;
