@@ -302,11 +302,11 @@ int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int
         p.pre_w = rawp(c, "base.pre_conv.weight"); p.pre_b = rawp(c, "base.pre_conv.bias");
     }
     p.w_wino = rb.u1;
-    const bool wino1 = c->wino && !x0 && rb.u1 && lass_wino_supported(p);
+    const bool wino1 = c->wino && rb.u1 && lass_wino_supported(p);
     {
         ProfScope ps(c, st, P_CONV3X3);
         if (wino1)
-            HIP_TRY(c, lass_launch_wino(CONV1_ACT, p, st));
+            HIP_TRY(c, lass_launch_wino(x0 ? CONV1_ACT_PRE : CONV1_ACT, p, st));
         else
             HIP_TRY(c, lass_launch_conv(x0 ? CONV1_ACT_PRE : CONV1_ACT, p, st));
     }
@@ -315,7 +315,7 @@ int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int
     q.out = out; q.out_bs = out_bs; q.B = B; q.H = H; q.W = W;
     q.pool_out = pool_out; q.pool_h = pool_h;
     q.w_wino = rb.u2; q.w2_wino = rb.usc;
-    const bool wino2 = c->wino && !x0 && rb.u2 && lass_wino_supported(q);
+    const bool wino2 = c->wino && rb.u2 && lass_wino_supported(q);
     ProfScope ps(c, st, P_CONV3X3);
     if (rb.cin == rb.cout) {
         q.res = x; q.res_bs = x_bs;
@@ -324,7 +324,7 @@ int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int
             q.pre_w = rawp(c, "base.pre_conv.weight"); q.pre_b = rawp(c, "base.pre_conv.bias");
         }
         if (wino2)
-            HIP_TRY(c, lass_launch_wino(CONV2_IDENT, q, st));
+            HIP_TRY(c, lass_launch_wino(x0 ? CONV2_IDENT_PRE : CONV2_IDENT, q, st));
         else
             HIP_TRY(c, lass_launch_conv(x0 ? CONV2_IDENT_PRE : CONV2_IDENT, q, st));
     } else {
@@ -710,7 +710,7 @@ int lass_separate(lass_ctx* c, const float* mixture, const float* condition, flo
         HIP_TRY(c, lass_launch_film(condition, B, c->film_W, c->film_b, c->bn_base, c->n_shift, shift, st));
     }
     // pre_conv (resunet.py:555) is normally never materialised: encoder_block1 forms it from x0 while staging
-    const bool fuse_pre = c->fuse_preconv && !c->wino;  // the Winograd kernels read a materialised block input
+    const bool fuse_pre = c->fuse_preconv;
     if (!fuse_pre) {
         ProfScope ps(c, st, P_PRECONV);
         HIP_TRY(c, lass_launch_preconv(F(pl.x0), rawp(c, "base.pre_conv.weight"), rawp(c, "base.pre_conv.bias"), B,

@@ -27,6 +27,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int F_PRO = 1, F_PHASEB = 2, F_BIAS = 4, F_RES = 8, F_EPIACT = 16;
+constexpr int F_PRECONV = 64;   // input is the 1-channel x0; channel c = pre_w[c]*x0 + pre_b[c] is formed while staging
+constexpr int F_RESPRE = 128;   // with F_RES: the residual is pre_w[n]*x0 + pre_b[n]
 constexpr int NTHREADS = 256;
 constexpr int KC = 8;
 constexpr int PWT = 16;  // Winograd tiles per row pair (32 output columns)
@@ -34,7 +36,7 @@ constexpr int PWT = 16;  // Winograd tiles per row pair (32 output columns)
 __device__ __forceinline__ float leaky(float v) { return fmaxf(v, 0.01f * v); }
 
 // Halo-tile staging: [KC][IR][IP] raw (activated) input, walked in channel pairs (see conv.hip Phase).
-template <int IR, int IP, int HALO, int KCH, bool PRO>
+template <int IR, int IP, int HALO, int KCH, bool PRO, bool PRE = false>
 struct RawStage {
     static constexpr int CH_ELEMS = IR * IP;
     static constexpr int G = 2;
@@ -43,7 +45,7 @@ struct RawStage {
     static constexpr int NPASS = (GRP_ELEMS + NTHREADS - 1) / NTHREADS;
     int goff[NPASS];
     unsigned okbits;
-    float v[2][NGRP][NPASS];  // two chunks in flight: chunk c+2 is requested while chunk c is contracted
+    float v[PRE ? 1 : 2][PRE ? 1 : NGRP][NPASS];  // two chunks in flight (PRE: x0 at this thread's positions, loaded once)
 
     __device__ __forceinline__ static int upos(int tid, int k) {
         const int u = tid + k * NTHREADS;
@@ -66,16 +68,32 @@ struct RawStage {
     static constexpr int NLOADS = NGRP * NPASS;  // vector-memory loads load() issues (counted by the vmcnt waits)
     template <int BUF>
     __device__ __forceinline__ void load(const float* __restrict__ in_c0, int HW) {
+        if (PRE) return;  // nothing per chunk: every channel is an affine function of the one x0 plane
 #pragma unroll
         for (int q = 0; q < NGRP; ++q)
 #pragma unroll
             for (int k = 0; k < NPASS; ++k) v[BUF][q][k] = in_c0[(size_t)q * G * HW + goff[k]];
     }
+    __device__ __forceinline__ void load_x0(const float* __restrict__ x0_b, int HW) {  // PRE only
+#pragma unroll
+        for (int k = 0; k < NPASS; ++k) v[0][0][k] = x0_b[goff[k] >= HW ? goff[k] - HW : goff[k]];
+    }
     // lsc / lsh: the prologue scale / shift of this chunk's channels in LDS (staged once per workgroup); all table reads
     // are issued up front (uniform b128 reads) so the element loop below has no LDS read behind an LDS write.
+    // PRE: lpw / lpb = pre_conv weight / bias of this chunk's channels (LDS), else unused
     template <int BUF>
-    __device__ __forceinline__ void store(float* lds, const float* lsc, const float* lsh, int tid) {
-        float tsc[KCH], tsh[KCH];
+    __device__ __forceinline__ void store(float* lds, const float* lsc, const float* lsh, int tid,
+                                          const float* lpw = nullptr, const float* lpb = nullptr) {
+        float tsc[KCH], tsh[KCH], tpw[KCH], tpb[KCH];
+        if (PRE) {
+#pragma unroll
+            for (int c = 0; c < KCH; c += 4) {
+                const float4 a = *reinterpret_cast<const float4*>(lpw + c);
+                const float4 b = *reinterpret_cast<const float4*>(lpb + c);
+                tpw[c] = a.x; tpw[c + 1] = a.y; tpw[c + 2] = a.z; tpw[c + 3] = a.w;
+                tpb[c] = b.x; tpb[c + 1] = b.y; tpb[c + 2] = b.z; tpb[c + 3] = b.w;
+            }
+        }
         if (PRO) {
 #pragma unroll
             for (int c = 0; c < KCH; c += 4) {
@@ -90,7 +108,11 @@ struct RawStage {
 #pragma unroll
             for (int k = 0; k < NPASS; ++k) {
                 const int u = upos(tid, k);
-                float t = v[BUF][q][k];
+                float t = PRE ? 0.f : v[PRE ? 0 : BUF][PRE ? 0 : q][k];
+                if (PRE) {
+                    const bool hi0 = u >= CH_ELEMS;
+                    t = v[0][0][k] * (hi0 ? tpw[q * G + 1] : tpw[q * G]) + (hi0 ? tpb[q * G + 1] : tpb[q * G]);
+                }
                 if (PRO) {
                     const bool hi = u >= CH_ELEMS;
                     t = leaky(t * (hi ? tsc[q * G + 1] : tsc[q * G]) + (hi ? tsh[q * G + 1] : tsh[q * G]));
@@ -181,12 +203,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
     constexpr bool EPI = (FLAGS & F_EPIACT) != 0;
     constexpr bool BIAS = (FLAGS & F_BIAS) != 0;
     constexpr bool RES = (FLAGS & F_RES) != 0;
+    constexpr bool PRE = (FLAGS & F_PRECONV) != 0;
+    constexpr bool RESPRE = (FLAGS & F_RESPRE) != 0;
     constexpr int NT = 32 * WCO;
     constexpr int NWT = 16 * WWT;
     constexpr int OR_ = 2 * WWT, OC = 2 * PWT;  // output rows / cols of the block
     constexpr int IR = OR_ + 2, IP = OC + 2;
     constexpr int VP = NWT + 16;  // V row pitch (floats): spreads the 4 k-rows of a fragment read over the banks
-    using RA = RawStage<IR, IP, 1, KC, PRO>;
+    using RA = RawStage<IR, IP, 1, KC, PRO, PRE>;
     using RB = RawStage<OR_, OC, 0, KC, false>;
     using UA = UDma<16, NT>;
     using UB = UDma<4, NT>;
@@ -194,7 +218,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
     constexpr int V_F = 16 * KC * VP;
     constexpr int U_F = 16 * KC * NT;
     constexpr int MAXC = 768;  // largest Cin of a 3x3 conv in the network (decoder_block1/2.conv1)
-    constexpr int NTAB = (EPI ? 2 * NT : 0) + (BIAS ? NT : 0) + (PRO ? 2 * MAXC : 0);
+    constexpr int NTAB = (EPI ? 2 * NT : 0) + (BIAS ? NT : 0) + (PRO ? 2 * MAXC : 0) + ((PRE || RESPRE) ? 64 : 0);
     static_assert(RAW_F % 4 == 0 && V_F % 4 == 0, "16-B alignment of the LDS regions");
 
     __shared__ __attribute__((aligned(16))) float lds[RAW_F + V_F + U_F + NTAB];
@@ -206,6 +230,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
     float* lds_bias = lu + U_F + (EPI ? 2 * NT : 0);
     float* lds_sc = lu + U_F + (EPI ? 2 * NT : 0) + (BIAS ? NT : 0);  // PRO: scale / shift of every input channel
     float* lds_sh = lds_sc + MAXC;
+    float* lds_pw = lu + U_F + (EPI ? 2 * NT : 0) + (BIAS ? NT : 0) + (PRO ? 2 * MAXC : 0);  // pre_conv weight / bias (32+32)
+    float* lds_pb = lds_pw + 32;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -229,6 +255,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
             lds_sc[c] = sc[c];
             lds_sh[c] = sh[c];
         }
+    }
+    if ((PRE || RESPRE) && tid < 32) {
+        lds_pw[tid] = p.pre_w[tid];
+        lds_pb[tid] = p.pre_b[tid];
     }
 
 #ifdef LASS_CONV_DIAG
@@ -258,6 +288,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
         RA ra;
         ra.init(tid, y0, x0, p.H, p.W);
         const int nch = p.Cin / KC;  // even (host-checked)
+        if (PRE) ra.load_x0(in_b, HW);
         ra.template load<0>(in_b, HW);
         ra.template load<1>(in_b + (size_t)KC * HW, HW);
         const float* ulane = UA::lane_base(p.w_wino, p.Nw, n0, lane);
@@ -271,7 +302,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
 #ifdef LASS_CONV_DIAG
             const long long t1 = clock64();
 #endif
-            ra.template store<BUF>(lraw, lds_sc + ch * KC, lds_sh + ch * KC, tid);
+            ra.template store<BUF>(lraw, lds_sc + ch * KC, lds_sh + ch * KC, tid, lds_pw + ch * KC, lds_pb + ch * KC);
             __builtin_amdgcn_sched_barrier(0);
             UA::issue(ulane, p.Cin, p.Nw, ch * KC, lu_addr, wave);
             __builtin_amdgcn_sched_barrier(0);
@@ -320,7 +351,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
 #ifdef LASS_CONV_DIAG
             const long long t4 = clock64();
 #endif
-            if (pf)
+            if (pf && !PRE)
                 wait_vmcnt<RA::NLOADS>();  // this wave's U(ch) rows have landed; raw(ch+2) may still be in flight
             else
                 wait_vmcnt<0>();
@@ -420,9 +451,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
                 y[0][0] += bb; y[0][1] += bb; y[1][0] += bb; y[1][1] += bb;
             }
             if (RES) {
-                const float* rp = p.res + (size_t)b * p.res_bs + (size_t)n * HW + (size_t)min(oy, p.H - 1) * p.W + ox;
-                const float2 r0 = *reinterpret_cast<const float2*>(rp);
-                const float2 r1 = *reinterpret_cast<const float2*>(rp + (oy + 1 < p.H ? p.W : 0));
+                const float* rp = p.res + (size_t)b * p.res_bs + (RESPRE ? 0 : (size_t)n * HW) +
+                                  (size_t)min(oy, p.H - 1) * p.W + ox;
+                float2 r0 = *reinterpret_cast<const float2*>(rp);
+                float2 r1 = *reinterpret_cast<const float2*>(rp + (oy + 1 < p.H ? p.W : 0));
+                if (RESPRE) {  // residual = pre_conv(x0): resunet.py:555,165
+                    const float pw = lds_pw[nl], pb = lds_pb[nl];
+                    r0.x = r0.x * pw + pb; r0.y = r0.y * pw + pb; r1.x = r1.x * pw + pb; r1.y = r1.y * pw + pb;
+                }
                 y[0][0] += r0.x; y[0][1] += r0.y; y[1][0] += r1.x; y[1][1] += r1.y;
             }
             if (EPI) {
@@ -550,6 +586,14 @@ hipError_t lass_launch_wino(ConvKind kind, const ConvArgs& p, hipStream_t stream
         case CONV2_SHORTCUT:
             if (!p.in2 || !p.w2_wino || !p.bias || p.Cin2 % (2 * KC) != 0) return hipErrorInvalidValue;
             return launch_wino<F_PHASEB | F_BIAS>(p, stream);
+        case CONV1_ACT_PRE:
+            if (!p.pro_scale || !p.pro_shift || !p.epi_scale || !p.epi_shift || !p.pre_w || !p.pre_b || p.N != 32 ||
+                p.Cin != 32)
+                return hipErrorInvalidValue;
+            return launch_wino<F_PRO | F_EPIACT | F_PRECONV>(p, stream);
+        case CONV2_IDENT_PRE:
+            if (!p.res || !p.pre_w || !p.pre_b || p.N != 32) return hipErrorInvalidValue;
+            return launch_wino<F_RES | F_RESPRE>(p, stream);
         default:
             return hipErrorInvalidValue;
     }

@@ -10,7 +10,7 @@ import re
 txt=open('build.log').read()
 for b in re.split(r'remark: Function Name: ', txt)[1:]:
     name=b.split()[0]
-    m=re.search(r'(wino_kernel|conv_kernel_sb|conv_kernel_db)I(.*?)EEv', name)
+    m=re.search(r'(wino_kernel_p|wino_kernel|conv_kernel_sb|conv_kernel_db)I(.*?)EEv', name)
     if not m or 'wino' not in m.group(1): continue
     g=lambda k: re.search(k+r': (\d+)', b).group(1)
     print(m.group(1), re.findall(r'Li(\d+)E', name), 'VGPR',g('VGPRs'),'AGPR',g('AGPRs'),'occ',g(r'Occupancy \[waves/SIMD\]'),'spill',g('VGPRs Spill'),'scratch',g(r'ScratchSize \[bytes/lane\]'),'LDS',g(r'LDS Size \[bytes/block\]'))
