@@ -18,8 +18,8 @@ def per_dispatch(path, counter):
     return list(d.values())
 
 def main(fetch_csv, write_csv, out_json, launches_per_step=26):
-    f = [e for e in per_dispatch(fetch_csv, 'FETCH_SIZE') if 'conv_kernel' in e['name'] and 'ILi1E' not in e['name']]
-    w = [e for e in per_dispatch(write_csv, 'WRITE_SIZE') if 'conv_kernel' in e['name'] and 'ILi1E' not in e['name']]
+    f = [e for e in per_dispatch(fetch_csv, 'FETCH_SIZE') if (('conv_kernel' in e['name'] and '<1,' not in e['name'] and 'ILi1E' not in e['name']) or 'wino_kernel' in e['name'])]
+    w = [e for e in per_dispatch(write_csv, 'WRITE_SIZE') if (('conv_kernel' in e['name'] and '<1,' not in e['name'] and 'ILi1E' not in e['name']) or 'wino_kernel' in e['name'])]
     f, w = f[-launches_per_step:], w[-launches_per_step:]
     fetch = sum(e['v'] for e in f) * 1024.0
     write = sum(e['v'] for e in w) * 1024.0
