@@ -22,6 +22,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -85,6 +86,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="clips per GPU per step (BASELINE configs[1]: 16)")
     ap.add_argument("--length", type=int, default=160000, help="samples per clip (10 s @ 16 kHz)")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="f32 = BASELINE configs[1] (headline); bf16 = configs[2] (bf16-MFMA convolutions)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     args = ap.parse_args()
@@ -109,7 +112,7 @@ def main():
     sd = synthetic.make_state_dict()
     model = ResUNet30(1, 1, 512)
     model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
-    model = model.to(dev).eval()
+    model = model.to(dev).eval().set_compute_dtype(args.dtype)
     eng = model.engine
     B, L = args.batch, args.length
     # distinct synthetic clips per rank; a small pool tiled to B keeps host-side generation short
@@ -164,26 +167,31 @@ def main():
             elif r["name"].endswith(".shortcut"):
                 exec_flops += 2.0 * B * r["macs"]
         executed = exec_flops / (per_step_ms * 1e-3) / 1e12 if per_step_ms > 0 else 0.0
+        peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
         res = {
             "metric": "clips/sec (10s@16kHz)", "value": world * B * args.steps / dt, "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"ResUNet30 separate() fp32, batch={B}/GPU, {L / 16000:.0f}s@16kHz clips, fixed "
-                                   "precomputed condition embedding, seeded random-init weights (BASELINE configs[1])",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"ResUNet30 separate() {'fp32' if args.dtype == 'f32' else 'bf16-MFMA convs (f32 storage/accumulate)'}, "
+                                   f"batch={B}/GPU, {L / 16000:.0f}s@16kHz clips, fixed precomputed condition embedding, "
+                                   f"seeded random-init weights (BASELINE configs[{1 if args.dtype == 'f32' else 2}])",
                        "clips_per_gpu_per_step": B, "samples_per_clip": L, "parallelism": f"clip-sharded x{world}"},
             "realtime_factor": world * B * args.steps / dt * (L / 16000.0),
             "roofline": {"bound": "mfma", "kernel": "conv3x3_mfma (3x3 convs + fused 1x1 shortcuts, f32 MFMA; achieved = algorithmic direct-conv FLOPs)",
-                         "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": traffic if args.dtype == "f32" else None,
                          "traffic_meta": traffic_meta,
-                         "algorithm": "Winograd F(2x2,3x3) on f32 MFMA for W>=32, direct below" if wino else "direct",
-                         "executed_tflops": executed, "executed_frac": executed / PEAK_F32_MFMA_TFLOPS,
+                         "algorithm": ("bf16 MFMA direct conv for W>=32 (staging-bound: f32 activations are converted while "
+                                       "staged), f32 direct below") if args.dtype == "bf16" else
+                                      ("Winograd F(2x2,3x3) on f32 MFMA for W>=32, direct below" if wino else "direct"),
+                         "executed_tflops": executed if args.dtype == "f32" else achieved,
+                         "executed_frac": (executed if args.dtype == "f32" else achieved) / peak,
                          "launches_per_step": launches / args.steps, "avg_launch_ms": ms / max(1, launches),
                          "algorithmic_gflop_per_step": conv_flops / 1e9,
                          "whole_step_tflops": total_flops / (dt / args.steps) / 1e12},
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.dtype == "f32":
             res["cpu_baseline"] = cpu_baseline(sd, L, args.cpu_seconds)
         print(json.dumps(res), flush=True)
     if world > 1:

@@ -42,7 +42,9 @@ typedef struct lass_ctx lass_ctx;
 #define LASS_I64 1
 
 /* compute modes for lass_finalize */
-#define LASS_COMPUTE_F32 0     /* f32 storage, v_mfma_f32_32x32x2_f32 contractions (bit-exact f32 FMA chains) */
+#define LASS_COMPUTE_F32 0     /* f32 storage, f32 MFMA contractions (plain f32 FMAs; Winograd F(2x2,3x3) for W >= 32) */
+#define LASS_COMPUTE_BF16 1    /* f32 storage, 3x3 convs at W >= 32 contracted on the bf16 MFMA (operands rounded to bf16,
+                                  f32 accumulate): BASELINE configs[2]; reduced precision, looser parity */
 
 /* Library / ABI version (major*10000 + minor*100 + patch). */
 int lass_version(void);

@@ -50,6 +50,7 @@ struct ResBlock {  // one ConvBlockRes
     int s1 = -1, s2 = -1;  // site indices
     float *w1 = nullptr, *w2 = nullptr, *wsc = nullptr;  // re-laid-out
     float *u1 = nullptr, *u2 = nullptr, *usc = nullptr;  // Winograd-domain copies (when enabled)
+    void *b1 = nullptr, *b2 = nullptr, *bsc16 = nullptr;  // bf16 copies (LASS_COMPUTE_BF16)
     const float* bsc = nullptr;                         // raw shortcut bias
 };
 
@@ -79,6 +80,7 @@ struct lass_ctx {
     int dec_site[6] = {0};           // decoder_blockN->beta1
     std::vector<void*> owned;        // derived device buffers to free
     // profiling
+    int compute_mode = LASS_COMPUTE_F32;
     bool wino = true;          // Winograd F(2x2,3x3) kernels for the 3x3 convs at W >= 32 (LASS_WINO=0: direct only)
     bool fuse_preconv = true;  // LASS_FUSE_PRECONV=0 materialises pre_conv's output with its own kernel
     bool fuse_pool = true;  // LASS_FUSE_POOL=0 selects the stand-alone pool kernel (A/B + parity of both paths)
@@ -302,10 +304,14 @@ int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int
         p.pre_w = rawp(c, "base.pre_conv.weight"); p.pre_b = rawp(c, "base.pre_conv.bias");
     }
     p.w_wino = rb.u1;
-    const bool wino1 = c->wino && rb.u1 && lass_wino_supported(p);
+    p.w_bf16 = rb.b1;
+    const bool bf1 = c->compute_mode == LASS_COMPUTE_BF16 && !x0 && rb.b1 && lass_bf16_supported(p);
+    const bool wino1 = !bf1 && c->wino && rb.u1 && lass_wino_supported(p);
     {
         ProfScope ps(c, st, P_CONV3X3);
-        if (wino1)
+        if (bf1)
+            HIP_TRY(c, lass_launch_conv_bf16(CONV1_ACT, p, st));
+        else if (wino1)
             HIP_TRY(c, lass_launch_wino(x0 ? CONV1_ACT_PRE : CONV1_ACT, p, st));
         else
             HIP_TRY(c, lass_launch_conv(x0 ? CONV1_ACT_PRE : CONV1_ACT, p, st));
@@ -315,7 +321,10 @@ int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int
     q.out = out; q.out_bs = out_bs; q.B = B; q.H = H; q.W = W;
     q.pool_out = pool_out; q.pool_h = pool_h;
     q.w_wino = rb.u2; q.w2_wino = rb.usc;
-    const bool wino2 = c->wino && rb.u2 && lass_wino_supported(q);
+    q.w_bf16 = rb.b2; q.w2_bf16 = rb.bsc16;
+    const bool bf2 = c->compute_mode == LASS_COMPUTE_BF16 && !x0 && rb.b2 && lass_bf16_supported(q) &&
+                     (rb.cin == rb.cout || (rb.bsc16 && rb.cin % 16 == 0));
+    const bool wino2 = !bf2 && c->wino && rb.u2 && lass_wino_supported(q);
     ProfScope ps(c, st, P_CONV3X3);
     if (rb.cin == rb.cout) {
         q.res = x; q.res_bs = x_bs;
@@ -323,13 +332,17 @@ int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int
             q.res = x0; q.res_bs = HW;
             q.pre_w = rawp(c, "base.pre_conv.weight"); q.pre_b = rawp(c, "base.pre_conv.bias");
         }
-        if (wino2)
+        if (bf2)
+            HIP_TRY(c, lass_launch_conv_bf16(CONV2_IDENT, q, st));
+        else if (wino2)
             HIP_TRY(c, lass_launch_wino(x0 ? CONV2_IDENT_PRE : CONV2_IDENT, q, st));
         else
             HIP_TRY(c, lass_launch_conv(x0 ? CONV2_IDENT_PRE : CONV2_IDENT, q, st));
     } else {
         q.in2 = x; q.in2_bs = x_bs; q.Cin2 = rb.cin; q.w2 = rb.wsc; q.bias = rb.bsc;
-        if (wino2)
+        if (bf2)
+            HIP_TRY(c, lass_launch_conv_bf16(CONV2_SHORTCUT, q, st));
+        else if (wino2)
             HIP_TRY(c, lass_launch_wino(CONV2_SHORTCUT, q, st));
         else
             HIP_TRY(c, lass_launch_conv(CONV2_SHORTCUT, q, st));
@@ -520,7 +533,9 @@ int lass_set_param(lass_ctx* c, const char* name_c, const void* data, const int6
 
 int lass_finalize(lass_ctx* c, int compute_mode) {
     if (!c) return LASS_ERR_ARG;
-    if (compute_mode != LASS_COMPUTE_F32) return fail(c, LASS_ERR_ARG, "unsupported compute mode");
+    if (compute_mode != LASS_COMPUTE_F32 && compute_mode != LASS_COMPUTE_BF16)
+        return fail(c, LASS_ERR_ARG, "unsupported compute mode");
+    c->compute_mode = compute_mode;
     HIP_TRY(c, hipSetDevice(c->device));
     free_owned(c);
     c->finalized = false;
@@ -564,7 +579,16 @@ int lass_finalize(lass_ctx* c, int compute_mode) {
         HIP_TRY(c, lass_launch_relayout_conv(w1, rb.cout, rb.cin, 9, rb.w1, st));
         HIP_TRY(c, lass_launch_relayout_conv(w2, rb.cout, rb.cout, 9, rb.w2, st));
         rb.u1 = rb.u2 = rb.usc = nullptr;
-        if (c->wino) {
+        rb.b1 = rb.b2 = rb.bsc16 = nullptr;
+        if (c->compute_mode == LASS_COMPUTE_BF16 && rb.cin % 16 == 0 && rb.cout % 16 == 0) {
+            unsigned short *t1 = nullptr, *t2 = nullptr;
+            if (dev_alloc(c, &t1, (size_t)rb.cout * rb.cin * 9) || dev_alloc(c, &t2, (size_t)rb.cout * rb.cout * 9))
+                return LASS_ERR_HIP;
+            HIP_TRY(c, lass_launch_weights_bf16(w1, rb.cout, rb.cin, 9, t1, st));
+            HIP_TRY(c, lass_launch_weights_bf16(w2, rb.cout, rb.cout, 9, t2, st));
+            rb.b1 = t1; rb.b2 = t2;
+        }
+        if (c->wino && c->compute_mode == LASS_COMPUTE_F32) {
             if (dev_alloc(c, &rb.u1, (size_t)16 * rb.cout * rb.cin) || dev_alloc(c, &rb.u2, (size_t)16 * rb.cout * rb.cout))
                 return LASS_ERR_HIP;
             HIP_TRY(c, lass_launch_wino_weights(w1, rb.cout, rb.cin, rb.u1, st));
@@ -578,7 +602,13 @@ int lass_finalize(lass_ctx* c, int compute_mode) {
             if (dev_alloc(c, &rb.wsc, (size_t)rb.cout * rb.cin)) return LASS_ERR_HIP;
             HIP_TRY(c, lass_launch_relayout_conv(ws, rb.cout, rb.cin, 1, rb.wsc, st));
             rb.bsc = bs;
-            if (c->wino) {
+            if (c->compute_mode == LASS_COMPUTE_BF16 && rb.b1) {
+                unsigned short* t3 = nullptr;
+                if (dev_alloc(c, &t3, (size_t)rb.cout * rb.cin)) return LASS_ERR_HIP;
+                HIP_TRY(c, lass_launch_weights_bf16(ws, rb.cout, rb.cin, 1, t3, st));
+                rb.bsc16 = t3;
+            }
+            if (c->wino && c->compute_mode == LASS_COMPUTE_F32) {
                 if (dev_alloc(c, &rb.usc, (size_t)4 * rb.cout * rb.cin)) return LASS_ERR_HIP;
                 HIP_TRY(c, lass_launch_wino_shortcut_weights(ws, rb.cout, rb.cin, rb.usc, st));
             }
@@ -710,7 +740,7 @@ int lass_separate(lass_ctx* c, const float* mixture, const float* condition, flo
         HIP_TRY(c, lass_launch_film(condition, B, c->film_W, c->film_b, c->bn_base, c->n_shift, shift, st));
     }
     // pre_conv (resunet.py:555) is normally never materialised: encoder_block1 forms it from x0 while staging
-    const bool fuse_pre = c->fuse_preconv;
+    const bool fuse_pre = c->fuse_preconv && c->compute_mode == LASS_COMPUTE_F32;  // bf16 kernels read a materialised input
     if (!fuse_pre) {
         ProfScope ps(c, st, P_PRECONV);
         HIP_TRY(c, lass_launch_preconv(F(pl.x0), rawp(c, "base.pre_conv.weight"), rawp(c, "base.pre_conv.bias"), B,

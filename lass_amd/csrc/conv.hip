@@ -23,23 +23,9 @@
 #include <cstdlib>
 #include <vector>
 #include "kernels.h"
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+#include "conv_common.h"
 
 namespace {
-
-constexpr int F_PRO = 1;     // prologue: x*scale[c] + shift[b][c], leaky 0.01
-constexpr int F_PHASEB = 2;  // second K-phase: 1x1 over raw in2 (shortcut conv)
-constexpr int F_BIAS = 4;    // + bias[n]            (as initial accumulator)
-constexpr int F_RES = 8;     // + res[b][n][y][x]    (as initial accumulator)
-constexpr int F_EPIACT = 16; // epilogue: leaky(v*scale[n] + shift[b][n])
-constexpr int F_TCONV = 32;  // n = (co, a, bb); scatter to (y*uh+a, x*uw+bb)
-constexpr int F_PRECONV = 64;   // input is the 1-channel x0; channel c = pre_w[c]*x0 + pre_b[c] is formed while staging
-constexpr int F_RESPRE = 128;   // with F_RES: the residual is pre_w[n]*x0 + pre_b[n] (never materialised)
-
-constexpr int NTHREADS = 256;
-
-__device__ __forceinline__ float leaky(float v) { return fmaxf(v, 0.01f * v); }  // == v > 0 ? v : 0.01 v
 
 // One K-phase: per chunk, [KC] channels x (rows+halo) x (cols+halo) of input and [KC][TAPS][NT] of weights are staged
 // in LDS; the registers of chunk c+1 are loaded from global memory while chunk c is contracted.
@@ -237,112 +223,6 @@ struct MaxI {
     static constexpr int v = A > B ? A : B;
 };
 
-
-// Transposed-conv scatter: n = co_real*(uh*2) + a*2 + bb; registers (r, r+1), r even, are bb = 0/1 of one (co_real, a),
-// so each lane writes 8 contiguous bytes and a half-wave a contiguous 256-B run of the up-sampled row.
-template <int NCO, int NPX, int PW>
-__device__ __forceinline__ void tconv_store(const ConvArgs& p, f32x16 (&acc)[NCO][NPX], int b, int n0, int y0, int x0,
-                                            int lane, int wave) {
-    constexpr int PH = 32 / PW, WROWS = NPX * PH;
-    const int HW = p.H * p.W;
-    const int khalf = lane >> 5, j = lane & 31;
-    const int ty = j / PW, tx = j % PW;
-    const int x = x0 + tx;
-    const int uhw = p.up_h * 2;
-    const size_t oHW = (size_t)HW * uhw;
-    const int oW = p.W * 2;
-#pragma unroll
-    for (int co = 0; co < NCO; ++co)
-#pragma unroll
-        for (int px = 0; px < NPX; ++px) {
-            const int y = y0 + wave * WROWS + px * PH + ty;
-            if (y >= p.H) continue;
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const int n = n0 + co * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                const int co_real = n / uhw, a = (n % uhw) >> 1;
-                float2 o = make_float2(acc[co][px][r], acc[co][px][r + 1]);
-                float* dst = p.out + (size_t)b * p.out_bs + co_real * oHW + (size_t)(y * p.up_h + a) * oW + x * 2;
-                *reinterpret_cast<float2*>(dst) = o;
-            }
-        }
-}
-
-// Final store of one wave's accumulators (non-transposed kernels): optional prefetched residual, optional epilogue
-// activation, and optionally the block's F.avg_pool2d (resunet.py:197) fused in: the 2x2 (or 1x2) window of a pooled
-// pixel is (px-tile 0, px-tile 1) x (lane, lane^1), summed in the reference's row-major order.
-template <int NCO, int NPX, int PW, int FLAGS, bool HAVE_RTMP>
-__device__ __forceinline__ void store_tile(const ConvArgs& p, f32x16 (&acc)[NCO][NPX], const float (*rtmp)[16],
-                                           const float* lds_es, const float* lds_eh, int b, int n0, int y0, int x0,
-                                           int lane, int wave) {
-    constexpr int PH = 32 / PW, WROWS = NPX * PH;
-    constexpr bool EPI = (FLAGS & F_EPIACT) != 0;
-    constexpr bool RES = (FLAGS & F_RES) != 0;
-    const int HW = p.H * p.W;
-    const int khalf = lane >> 5, j = lane & 31;
-    const int ty = j / PW, tx = j % PW;
-    const int x = x0 + tx;
-#pragma unroll
-    for (int co = 0; co < NCO; ++co) {
-        float val[NPX][16];
-#pragma unroll
-        for (int px = 0; px < NPX; ++px) {
-            const int y = y0 + wave * WROWS + px * PH + ty;
-            const size_t pix = (size_t)(n0 + co * 32 + 4 * khalf) * HW + (size_t)min(y, p.H - 1) * p.W + x;
-            float radd[16];
-            if (RES && !HAVE_RTMP) {  // batch of 16 unconditional loads, then one wait
-                const float* src = p.res + (size_t)b * p.res_bs + pix;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) radd[r] = src[(size_t)((r & 3) + 8 * (r >> 2)) * HW];
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int nl = (r & 3) + 8 * (r >> 2);  // + co*32 + 4*khalf
-                float v = acc[co][px][r];
-                if (RES && HAVE_RTMP) v += rtmp[px][r];
-                if (RES && !HAVE_RTMP) v += radd[r];
-                if (EPI) v = leaky(v * lds_es[co * 32 + 4 * khalf + nl] + lds_eh[co * 32 + 4 * khalf + nl]);
-                val[px][r] = v;
-            }
-            if (y < p.H) {
-                float* dst = p.out + (size_t)b * p.out_bs + pix;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) dst[(size_t)((r & 3) + 8 * (r >> 2)) * HW] = val[px][r];
-            }
-        }
-        if (p.pool_out) {  // wave-uniform
-            const int Wo = p.W / 2;
-            if (p.pool_h == 2) {
-                if (PW == 32 && NPX == 2) {
-                    const int y = y0 + wave * WROWS;  // even row of the pair (px-tile 0); px-tile 1 is y+1
-                    const int Ho = p.H / 2;
-                    float* dst = p.pool_out + ((size_t)b * p.N + n0 + co * 32 + 4 * khalf) * Ho * Wo +
-                                 (size_t)(y >> 1) * Wo + (x >> 1);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float o0 = __shfl_xor(val[0][r], 1, 64), o1 = __shfl_xor(val[NPX - 1][r], 1, 64);
-                        float sum = val[0][r] + o0;
-                        sum += val[NPX - 1][r];
-                        sum += o1;
-                        if (!(lane & 1) && y + 1 < p.H) dst[(size_t)((r & 3) + 8 * (r >> 2)) * Ho * Wo] = sum * 0.25f;
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int px = 0; px < NPX; ++px) {
-                    const int y = y0 + wave * WROWS + px * PH + ty;
-                    float* dst = p.pool_out + ((size_t)b * p.N + n0 + co * 32 + 4 * khalf) * p.H * Wo +
-                                 (size_t)min(y, p.H - 1) * Wo + (x >> 1);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float sum = val[px][r] + __shfl_xor(val[px][r], 1, 64);
-                        if (!(lane & 1) && y < p.H) dst[(size_t)((r & 3) + 8 * (r >> 2)) * p.H * Wo] = sum * 0.5f;
-                    }
-                }
-            }
-        }
-    }
-}
 
 // ---- single-tile kernel, double-buffered LDS (one barrier per chunk) --------------------------------------------------
 template <int TAPS, int NCO, int NPX, int PW, int FLAGS>

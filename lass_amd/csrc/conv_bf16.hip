@@ -1,0 +1,304 @@
+// conv_bf16.hip - BASELINE configs[2]: the 3x3 (+ fused 1x1 shortcut) convolutions on the bf16 MFMA.
+//
+// Same semantics, tensors (NCHW f32 in HBM), prologue / epilogue fusions and accumulator layout as conv.hip; only the
+// contraction runs on v_mfma_f32_32x32x16_bf16 (f32 accumulate, 16x the f32-MFMA rate).  Activations are rounded to
+// bf16 (RNE) while they are staged into LDS - after the f32 BN+FiLM+leaky prologue - and weights are converted once in
+// lass_finalize.  This is reduced precision by design (8-bit mantissa operands): it is selected only with
+// lass_finalize(ctx, LASS_COMPUTE_BF16) and has its own, looser parity tests.
+//
+// LDS images are K-contiguous so that BOTH operands of an MFMA are one conflict-free ds_read_b128:
+//   input   [cin-octet (2)][row][col][8 x bf16]      lane (h, p): octet h, pixel p  (+ tap shift = whole 16-B units)
+//   weights [tap][cin-octet (2)][cout][8 x bf16]     lane (h, n): octet h, cout n
+// A chunk is 16 input channels = one MFMA K; per chunk a wave issues TAPS x NCO x NPX MFMAs.
+#include <hip/hip_runtime.h>
+#include "conv_common.h"
+#include "kernels.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+constexpr int KB = 16;  // input channels per chunk
+
+template <int TAPS, int NCO, int NPX, int PW, bool PRO>
+struct Phase16 {
+    static constexpr int PH = 32 / PW;
+    static constexpr int WROWS = NPX * PH;
+    static constexpr int PHT = 4 * WROWS;
+    static constexpr int HALO = (TAPS == 9) ? 1 : 0;
+    static constexpr int IR = PHT + 2 * HALO;
+    static constexpr int IP = PW + 2 * HALO;
+    static constexpr int NT = 32 * NCO;
+    static constexpr int NPIX = IR * IP;
+    static constexpr int NPP = (NPIX + NTHREADS - 1) / NTHREADS;  // pixel passes (each thread: one pixel, 8 channels)
+    static constexpr int IN_U4 = 2 * NPIX;                        // 16-byte units
+    static constexpr int W_U4 = TAPS * 2 * NT;
+    static constexpr int NWLD = (W_U4 + NTHREADS - 1) / NTHREADS;
+    static constexpr int LDS_U4 = IN_U4 + W_U4;
+
+    int goff[NPP];
+    unsigned okbits;
+    float v[2][NPP][8];  // prefetched f32 activations: [octet][pass][channel in octet]
+    uint4 wv[NWLD];      // prefetched bf16 weights
+    float psc[KB], psh[KB];
+
+    __device__ __forceinline__ static int upos(int tid, int k) {
+        const int u = tid + k * NTHREADS;
+        return u < NPIX ? u : NPIX - 1;
+    }
+    __device__ __forceinline__ void init(int tid, int y0, int x0, int H, int W) {
+        okbits = 0;
+#pragma unroll
+        for (int k = 0; k < NPP; ++k) {
+            const int u = upos(tid, k);
+            const int r = u / IP, x = u % IP;
+            const int gy = y0 + r - HALO, gx = x0 + x - HALO;
+            const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
+            goff[k] = min(max(gy, 0), H - 1) * W + min(max(gx, 0), W - 1);
+            okbits |= (ok ? 1u : 0u) << k;
+        }
+    }
+    // in_c0: channel c0 of this clip (f32 planes); wb: this chunk's weight slab [tap][octet][Cout] in 16-B units, + n0
+    __device__ __forceinline__ void load(const float* __restrict__ in_c0, int HW, const uint4* __restrict__ wb,
+                                         int Cout, const float* __restrict__ sc, const float* __restrict__ sh,
+                                         int tid) {
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int k = 0; k < NPP; ++k)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[o][k][j] = in_c0[(size_t)(o * 8 + j) * HW + goff[k]];
+#pragma unroll
+        for (int i = 0; i < NWLD; ++i) {
+            const int e0 = tid + i * NTHREADS;
+            const int e = e0 < W_U4 ? e0 : W_U4 - 1;
+            const int row = e / NT, col = e % NT;  // row = tap*2 + octet
+            wv[i] = wb[(size_t)row * Cout + col];
+        }
+        if (PRO) {
+#pragma unroll
+            for (int c = 0; c < KB; ++c) {
+                psc[c] = sc[c];
+                psh[c] = sh[c];
+            }
+        }
+    }
+    __device__ __forceinline__ void store(uint4* lds, int tid) {
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int k = 0; k < NPP; ++k) {
+                const int u = upos(tid, k);
+                const bool ok = (okbits >> k) & 1u;
+                bf16x8 pk;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float t = v[o][k][j];
+                    if (PRO) t = leaky(t * psc[o * 8 + j] + psh[o * 8 + j]);
+                    pk[j] = (__bf16)(ok ? t : 0.f);  // conv zero padding comes after the activation
+                }
+                *reinterpret_cast<bf16x8*>(lds + o * NPIX + u) = pk;
+            }
+#pragma unroll
+        for (int i = 0; i < NWLD; ++i) {
+            const int e0 = tid + i * NTHREADS;
+            lds[IN_U4 + (e0 < W_U4 ? e0 : W_U4 - 1)] = wv[i];
+        }
+    }
+    __device__ __forceinline__ static void compute(const uint4* lds, f32x16 (&acc)[NCO][NPX], int lane, int wave) {
+        const int h = lane >> 5, j = lane & 31;
+        const int ty = j / PW, tx = j % PW;
+        const bf16x8* bbase = reinterpret_cast<const bf16x8*>(lds) + h * NPIX + (wave * WROWS + ty) * IP + tx;
+        const bf16x8* abase = reinterpret_cast<const bf16x8*>(lds) + IN_U4 + h * NT + j;
+        bf16x8 a[2][NCO], b[2][NPX];
+        auto rd = [&](int tap, bf16x8 (&aa)[NCO], bf16x8 (&bb)[NPX]) {
+#pragma unroll
+            for (int co = 0; co < NCO; ++co) aa[co] = abase[tap * 2 * NT + co * 32];
+#pragma unroll
+            for (int px = 0; px < NPX; ++px)
+                bb[px] = bbase[(px * PH + (TAPS == 9 ? tap / 3 : 0)) * IP + (TAPS == 9 ? tap % 3 : 0)];
+        };
+        rd(0, a[0], b[0]);
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            if (tap + 1 < TAPS) rd(tap + 1, a[(tap + 1) & 1], b[(tap + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int co = 0; co < NCO; ++co)
+#pragma unroll
+                for (int px = 0; px < NPX; ++px)
+                    acc[co][px] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tap & 1][co], b[tap & 1][px], acc[co][px],
+                                                                          0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+};
+
+template <int A, int B>
+struct MaxU {
+    static constexpr int v = A > B ? A : B;
+};
+
+template <int NCO, int NPX, int PW, int FLAGS>
+__global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
+    constexpr bool PRO = (FLAGS & F_PRO) != 0;
+    constexpr bool HASB = (FLAGS & F_PHASEB) != 0;
+    constexpr bool EPI = (FLAGS & F_EPIACT) != 0;
+    constexpr bool BIAS = (FLAGS & F_BIAS) != 0;
+    constexpr bool RES = (FLAGS & F_RES) != 0;
+    constexpr bool RES_PF = RES && NCO == 1;
+    using PA = Phase16<9, NCO, NPX, PW, PRO>;
+    using PB = Phase16<1, NCO, NPX, PW, false>;
+    constexpr int LDS_U4 = HASB ? MaxU<PA::LDS_U4, PB::LDS_U4>::v : PA::LDS_U4;
+    constexpr int PH = PA::PH, WROWS = PA::WROWS, PHT = PA::PHT, NT = PA::NT;
+    constexpr int NTAB = (EPI ? 2 * NT : 0) + (BIAS ? NT : 0);
+
+    __shared__ uint4 lds4[LDS_U4 + (NTAB + 3) / 4];
+    float* tabs = reinterpret_cast<float*>(lds4 + LDS_U4);
+    float* lds_es = tabs;
+    float* lds_eh = tabs + NT;
+    float* lds_bias = tabs + (EPI ? 2 * NT : 0);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.z;
+    const int n0 = blockIdx.y * NT;
+    const int tiles_x = p.W / PW;
+    const int y0 = (blockIdx.x / tiles_x) * PHT, x0 = (blockIdx.x % tiles_x) * PW;
+    const int HW = p.H * p.W;
+    const int khalf = lane >> 5, j = lane & 31;
+    const int ty = j / PW, tx = j % PW;
+    const int x = x0 + tx;
+    const int nA = p.Cin / KB;
+    const int nB = HASB ? p.Cin2 / KB : 0;
+    const float* in_b = p.in + (size_t)b * p.in_bs;
+    const float* in2_b = HASB ? p.in2 + (size_t)b * p.in2_bs : nullptr;
+    const float* sc = PRO ? p.pro_scale : nullptr;
+    const float* sh = PRO ? p.pro_shift + (size_t)b * p.pro_shift_bs : nullptr;
+    const uint4* wa = reinterpret_cast<const uint4*>(p.w_bf16) + n0;    // [chunk][tap][octet][Cout] 16-B units
+    const uint4* wb2 = HASB ? reinterpret_cast<const uint4*>(p.w2_bf16) + n0 : nullptr;
+
+    if (EPI && tid < NT) {
+        lds_es[tid] = p.epi_scale[n0 + tid];
+        lds_eh[tid] = p.epi_shift[(size_t)b * p.epi_shift_bs + n0 + tid];
+    }
+    if (BIAS && tid < NT) lds_bias[tid] = p.bias[n0 + tid];
+
+    PA pa;
+    PB pb;
+    auto loadA = [&](int c) {
+        pa.load(in_b + (size_t)c * KB * HW, HW, wa + (size_t)c * 9 * 2 * p.Nw, p.Nw, sc + c * KB, sh + c * KB, tid);
+    };
+    auto loadB = [&](int c) {
+        pb.load(in2_b + (size_t)c * KB * HW, HW, wb2 + (size_t)c * 2 * p.Nw, p.Nw, nullptr, nullptr, tid);
+    };
+
+    pa.init(tid, y0, x0, p.H, p.W);
+    loadA(0);
+    __syncthreads();
+    pa.store(lds4, tid);
+    __syncthreads();
+
+    f32x16 acc[NCO][NPX];
+#pragma unroll
+    for (int co = 0; co < NCO; ++co)
+#pragma unroll
+        for (int px = 0; px < NPX; ++px)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                acc[co][px][r] = BIAS ? lds_bias[co * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf] : 0.f;
+
+    for (int ch = 0; ch + 1 < nA; ++ch) {
+        loadA(ch + 1);
+        PA::compute(lds4, acc, lane, wave);
+        __syncthreads();
+        pa.store(lds4, tid);
+        __syncthreads();
+    }
+    float rtmp[RES_PF ? NPX : 1][16];
+    if (HASB) {
+        pb.init(tid, y0, x0, p.H, p.W);
+        loadB(0);
+    }
+    if (RES_PF) {
+#pragma unroll
+        for (int px = 0; px < NPX; ++px) {
+            const int y = min(y0 + wave * WROWS + px * PH + ty, p.H - 1);
+            const float* src = p.res + (size_t)b * p.res_bs + (size_t)(n0 + 4 * khalf) * HW + (size_t)y * p.W + x;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rtmp[px][r] = src[(size_t)((r & 3) + 8 * (r >> 2)) * HW];
+        }
+    }
+    PA::compute(lds4, acc, lane, wave);
+    if (HASB) {
+        __syncthreads();
+        pb.store(lds4, tid);
+        __syncthreads();
+        for (int ch = 0; ch + 1 < nB; ++ch) {
+            loadB(ch + 1);
+            PB::compute(lds4, acc, lane, wave);
+            __syncthreads();
+            pb.store(lds4, tid);
+            __syncthreads();
+        }
+        PB::compute(lds4, acc, lane, wave);
+    }
+    store_tile<NCO, NPX, PW, FLAGS, RES_PF>(p, acc, rtmp, lds_es, lds_eh, b, n0, y0, x0, lane, wave);
+}
+
+// dst[chunk][tap][octet][Cout][8] (bf16, RNE) = src[co][ci = chunk*16 + octet*8 + j][tap]   (taps = 9 or 1)
+__global__ __launch_bounds__(256) void weights_bf16_kernel(const float* __restrict__ src, int Cout, int Cin, int taps,
+                                                           __bf16* __restrict__ dst) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long n = (long)Cout * Cin * taps;
+    if (i >= n) return;
+    const int jj = (int)(i % 8);
+    const int co = (int)((i / 8) % Cout);
+    const int o = (int)((i / (8L * Cout)) % 2);
+    const int tap = (int)((i / (16L * Cout)) % taps);
+    const int chunk = (int)(i / (16L * Cout * taps));
+    const int ci = chunk * 16 + o * 8 + jj;
+    dst[i] = (__bf16)src[((size_t)co * Cin + ci) * taps + tap];
+}
+
+template <int FLAGS>
+hipError_t launch_bf16(const ConvArgs& p, hipStream_t stream) {
+    if (p.N % 64 == 0) {
+        dim3 grid((p.W / 32) * ((p.H + 7) / 8), p.N / 64, p.B);
+        hipLaunchKernelGGL((conv_bf16_kernel<2, 2, 32, FLAGS>), grid, dim3(NTHREADS), 0, stream, p);
+    } else {
+        dim3 grid((p.W / 32) * ((p.H + 7) / 8), p.N / 32, p.B);
+        hipLaunchKernelGGL((conv_bf16_kernel<1, 2, 32, FLAGS>), grid, dim3(NTHREADS), 0, stream, p);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace
+
+bool lass_bf16_supported(const ConvArgs& p) {
+    return p.W >= 32 && (p.W % 32) == 0 && p.Cin % 16 == 0 && p.N % 32 == 0;
+}
+
+hipError_t lass_launch_conv_bf16(ConvKind kind, const ConvArgs& p, hipStream_t stream) {
+    if (!lass_bf16_supported(p) || !p.w_bf16 || !p.in || !p.out) return hipErrorInvalidValue;
+    switch (kind) {
+        case CONV1_ACT:
+            if (!p.pro_scale || !p.pro_shift || !p.epi_scale || !p.epi_shift) return hipErrorInvalidValue;
+            return launch_bf16<F_PRO | F_EPIACT>(p, stream);
+        case CONV2_IDENT:
+            if (!p.res) return hipErrorInvalidValue;
+            return launch_bf16<F_RES>(p, stream);
+        case CONV2_SHORTCUT:
+            if (!p.in2 || !p.w2_bf16 || !p.bias || p.Cin2 % 16 != 0) return hipErrorInvalidValue;
+            return launch_bf16<F_PHASEB | F_BIAS>(p, stream);
+        default:
+            return hipErrorInvalidValue;
+    }
+}
+
+hipError_t lass_launch_weights_bf16(const float* w, int Cout, int Cin, int taps, void* dst, hipStream_t stream) {
+    const long n = (long)Cout * Cin * taps;
+    hipLaunchKernelGGL(weights_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, w, Cout, Cin, taps,
+                       (__bf16*)dst);
+    return hipGetLastError();
+}

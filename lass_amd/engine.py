@@ -63,14 +63,20 @@ class Engine:
         self.finalized = False
         return _lib.check(self.ctx, rc, f"lass_set_param({name})")
 
-    def load_state_dict(self, sd: Dict[str, object]):
+    COMPUTE_MODES = {"f32": 0, "bf16": 1}  # include/lass_hip.h: LASS_COMPUTE_F32 / LASS_COMPUTE_BF16
+
+    def load_state_dict(self, sd: Dict[str, object], compute_dtype: str = "f32"):
         for k, v in sd.items():
             self.set_param(k, v)
-        self.finalize()
+        self.finalize(compute_dtype)
 
-    def finalize(self):
-        _lib.check(self.ctx, self.lib.lass_finalize(self.ctx, 0), "lass_finalize")
+    def finalize(self, compute_dtype: str = "f32"):
+        """compute_dtype 'f32' (default; exact-f32 MFMA arithmetic) or 'bf16' (BASELINE configs[2]: 3x3 convs on the
+        bf16 MFMA, f32 accumulate - reduced precision)."""
+        mode = self.COMPUTE_MODES[compute_dtype]
+        _lib.check(self.ctx, self.lib.lass_finalize(self.ctx, mode), "lass_finalize")
         self.finalized = True
+        self.compute_dtype = compute_dtype
 
     # ---- hot path --------------------------------------------------------------------------------------------
     def workspace_bytes(self, B: int, L: int) -> int:

@@ -63,6 +63,7 @@ class ResUNet30(nn.Module):
                 mod.register_parameter(parts[-1], nn.Parameter(t, requires_grad=False))
         self._engine: Optional[Engine] = None
         self._uploaded_sig = None
+        self.compute_dtype = "f32"  # "bf16" = BASELINE configs[2] (bf16-MFMA convolutions, reduced precision)
         self.eval()
 
     @staticmethod
@@ -84,8 +85,15 @@ class ResUNet30(nn.Module):
         self._uploaded_sig = None
         return r
 
+    def set_compute_dtype(self, compute_dtype: str) -> "ResUNet30":
+        if compute_dtype not in Engine.COMPUTE_MODES:
+            raise ValueError(f"compute_dtype must be one of {sorted(Engine.COMPUTE_MODES)}")
+        self.compute_dtype = compute_dtype
+        self._uploaded_sig = None
+        return self
+
     def _signature(self):
-        return tuple((t.data_ptr(), t._version) for t in self.state_dict(keep_vars=True).values())
+        return (self.compute_dtype,) + tuple((t.data_ptr(), t._version) for t in self.state_dict(keep_vars=True).values())
 
     def _device(self) -> torch.device:
         return self.base.pre_conv.weight.device
@@ -100,7 +108,7 @@ class ResUNet30(nn.Module):
             self._uploaded_sig = None
         sig = self._signature()
         if sig != self._uploaded_sig:
-            self._engine.load_state_dict({k: v for k, v in self.state_dict().items()})
+            self._engine.load_state_dict({k: v for k, v in self.state_dict().items()}, self.compute_dtype)
             self._uploaded_sig = sig
         return self._engine
 

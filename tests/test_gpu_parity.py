@@ -319,3 +319,39 @@ def test_evaluator_matches_oracle(tmp_path, model, oracle_sd):
     (o_sisdr, o_sdri, o_sdr), rows = oev.evaluate(oracle_sd, clips, conds)
     np.testing.assert_allclose(ev.last_rows, rows, atol=0.01)
     assert abs(sdr - o_sdr) < 0.01 and abs(sdri - o_sdri) < 0.01 and abs(sisdr - o_sisdr) < 0.01
+
+
+# ---- BASELINE configs[2]: bf16-MFMA convolutions (reduced precision by design; its own tolerances) --------------------
+def test_bf16_mode_convblock_and_waveform(synthetic_sd, oracle_sd):
+    """Operands of the 3x3 convs are rounded to bf16 (8-bit mantissa, ~4e-3 relative each): per-block outputs must
+    agree with the f32 oracle to ~1e-2 relative RMS and the end-to-end waveform to ~5e-2 relative RMS; SDR against the
+    oracle's waveform must exceed 25 dB.  (The f32 path is held to 2e-6.)"""
+    from lass_amd.engine import Engine
+    from lass_amd.resunet import ResUNet30
+    from oracle import resunet as orr
+    e = Engine(DEV)
+    e.load_state_dict(synthetic_sd, "bf16")
+    g = torch.Generator().manual_seed(11)
+    B = 2
+    cond = torch.from_numpy(synthetic.make_condition(B))
+    shift = e.film(cond.to(DEV))
+    for prefix, stem, cin, cout, H, W in [("base.encoder_block1.conv_block1", "encoder_block1->conv_block1", 32, 32, 40, 64),
+                                          ("base.encoder_block3.conv_block1", "encoder_block3->conv_block1", 64, 128, 16, 32),
+                                          ("base.decoder_block5.conv_block2", "decoder_block5->conv_block2", 128, 64, 24, 96)]:
+        x = torch.randn(B, cin, H, W, generator=g)
+        y = e.convblock(prefix, x.to(DEV), shift, cout).cpu()
+        ref = orr.conv_block_res(oracle_sd, prefix, x, orr.film(oracle_sd, cond, stem + "->beta1"),
+                                 orr.film(oracle_sd, cond, stem + "->beta2"))
+        rel = _relerr(y, ref)
+        assert 1e-5 < rel < 2e-2, (prefix, rel)   # > 1e-5: make sure the bf16 kernels really ran
+    m = ResUNet30(1, 1, 512)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synthetic_sd.items()})
+    m = m.to(DEV).eval().set_compute_dtype("bf16")
+    _, mix = synthetic.make_mixtures(2, 16000)
+    c2 = synthetic.make_condition(2)
+    out = m({"mixture": torch.from_numpy(mix)[:, None, :].to(DEV), "condition": torch.from_numpy(c2).to(DEV)})["waveform"]
+    ref = orr.forward(oracle_sd, {"mixture": torch.from_numpy(mix)[:, None, :], "condition": torch.from_numpy(c2)})[
+        "waveform"]
+    rel = _relerr(out, ref)
+    print("bf16 waveform relative RMS error", rel)
+    assert rel < 5e-2, rel

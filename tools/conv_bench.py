@@ -10,7 +10,7 @@ from lass_amd.engine import Engine
 ap = argparse.ArgumentParser(); ap.add_argument('--iters', type=int, default=5); ap.add_argument('--only', default='')
 ap.add_argument('--batch', type=int, default=16)
 a = ap.parse_args()
-eng = Engine('cuda:0'); eng.load_state_dict(synthetic.make_state_dict())
+eng = Engine('cuda:0'); eng.load_state_dict(synthetic.make_state_dict(), os.environ.get('LASS_COMPUTE', 'f32'))
 B = a.batch
 shift = eng.film(torch.from_numpy(synthetic.make_condition(B)).cuda())
 h, w = 1024, 512
