@@ -86,7 +86,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="clips per GPU per step (BASELINE configs[1]: 16)")
     ap.add_argument("--length", type=int, default=160000, help="samples per clip (10 s @ 16 kHz)")
-    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+    ap.add_argument("--dtype", choices=["f32", "bf16", "bf16x3"], default="f32",
                     help="f32 = BASELINE configs[1] (headline); bf16 = configs[2] (bf16-MFMA convolutions)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)

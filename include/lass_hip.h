@@ -45,6 +45,8 @@ typedef struct lass_ctx lass_ctx;
 #define LASS_COMPUTE_F32 0     /* f32 storage, f32 MFMA contractions (plain f32 FMAs; Winograd F(2x2,3x3) for W >= 32) */
 #define LASS_COMPUTE_BF16 1    /* f32 storage, 3x3 convs at W >= 32 contracted on the bf16 MFMA (operands rounded to bf16,
                                   f32 accumulate): BASELINE configs[2]; reduced precision, looser parity */
+#define LASS_COMPUTE_BF16X3 2  /* as BF16 but every operand is split hi+lo (two bf16) and each product formed as
+                                  hi*hi + hi*lo + lo*hi on the bf16 MFMA: ~16 mantissa bits per operand */
 
 /* Library / ABI version (major*10000 + minor*100 + patch). */
 int lass_version(void);

@@ -50,7 +50,8 @@ struct ResBlock {  // one ConvBlockRes
     int s1 = -1, s2 = -1;  // site indices
     float *w1 = nullptr, *w2 = nullptr, *wsc = nullptr;  // re-laid-out
     float *u1 = nullptr, *u2 = nullptr, *usc = nullptr;  // Winograd-domain copies (when enabled)
-    void *b1 = nullptr, *b2 = nullptr, *bsc16 = nullptr;  // bf16 copies (LASS_COMPUTE_BF16)
+    void *b1 = nullptr, *b2 = nullptr, *bsc16 = nullptr;  // bf16 copies (LASS_COMPUTE_BF16 / _BF16X3)
+    void *b1l = nullptr, *b2l = nullptr, *bscl = nullptr;  // lo halves of the hi+lo split (LASS_COMPUTE_BF16X3)
     const float* bsc = nullptr;                         // raw shortcut bias
 };
 
@@ -304,8 +305,8 @@ int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int
         p.pre_w = rawp(c, "base.pre_conv.weight"); p.pre_b = rawp(c, "base.pre_conv.bias");
     }
     p.w_wino = rb.u1;
-    p.w_bf16 = rb.b1;
-    const bool bf1 = c->compute_mode == LASS_COMPUTE_BF16 && !x0 && rb.b1 && lass_bf16_supported(p);
+    p.w_bf16 = rb.b1; p.w_bf16_lo = rb.b1l;
+    const bool bf1 = c->compute_mode != LASS_COMPUTE_F32 && !x0 && rb.b1 && lass_bf16_supported(p);
     const bool wino1 = !bf1 && c->wino && rb.u1 && lass_wino_supported(p);
     {
         ProfScope ps(c, st, P_CONV3X3);
@@ -321,8 +322,8 @@ int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int
     q.out = out; q.out_bs = out_bs; q.B = B; q.H = H; q.W = W;
     q.pool_out = pool_out; q.pool_h = pool_h;
     q.w_wino = rb.u2; q.w2_wino = rb.usc;
-    q.w_bf16 = rb.b2; q.w2_bf16 = rb.bsc16;
-    const bool bf2 = c->compute_mode == LASS_COMPUTE_BF16 && !x0 && rb.b2 && lass_bf16_supported(q) &&
+    q.w_bf16 = rb.b2; q.w2_bf16 = rb.bsc16; q.w_bf16_lo = rb.b2l; q.w2_bf16_lo = rb.bscl;
+    const bool bf2 = c->compute_mode != LASS_COMPUTE_F32 && !x0 && rb.b2 && lass_bf16_supported(q) &&
                      (rb.cin == rb.cout || (rb.bsc16 && rb.cin % 16 == 0));
     const bool wino2 = !bf2 && c->wino && rb.u2 && lass_wino_supported(q);
     ProfScope ps(c, st, P_CONV3X3);
@@ -533,7 +534,7 @@ int lass_set_param(lass_ctx* c, const char* name_c, const void* data, const int6
 
 int lass_finalize(lass_ctx* c, int compute_mode) {
     if (!c) return LASS_ERR_ARG;
-    if (compute_mode != LASS_COMPUTE_F32 && compute_mode != LASS_COMPUTE_BF16)
+    if (compute_mode != LASS_COMPUTE_F32 && compute_mode != LASS_COMPUTE_BF16 && compute_mode != LASS_COMPUTE_BF16X3)
         return fail(c, LASS_ERR_ARG, "unsupported compute mode");
     c->compute_mode = compute_mode;
     HIP_TRY(c, hipSetDevice(c->device));
@@ -579,14 +580,24 @@ int lass_finalize(lass_ctx* c, int compute_mode) {
         HIP_TRY(c, lass_launch_relayout_conv(w1, rb.cout, rb.cin, 9, rb.w1, st));
         HIP_TRY(c, lass_launch_relayout_conv(w2, rb.cout, rb.cout, 9, rb.w2, st));
         rb.u1 = rb.u2 = rb.usc = nullptr;
-        rb.b1 = rb.b2 = rb.bsc16 = nullptr;
-        if (c->compute_mode == LASS_COMPUTE_BF16 && rb.cin % 16 == 0 && rb.cout % 16 == 0) {
+        rb.b1 = rb.b2 = rb.bsc16 = rb.b1l = rb.b2l = rb.bscl = nullptr;
+        const bool bfm = c->compute_mode == LASS_COMPUTE_BF16 || c->compute_mode == LASS_COMPUTE_BF16X3;
+        const bool split = c->compute_mode == LASS_COMPUTE_BF16X3;
+        if (bfm && rb.cin % 16 == 0 && rb.cout % 16 == 0) {
             unsigned short *t1 = nullptr, *t2 = nullptr;
             if (dev_alloc(c, &t1, (size_t)rb.cout * rb.cin * 9) || dev_alloc(c, &t2, (size_t)rb.cout * rb.cout * 9))
                 return LASS_ERR_HIP;
-            HIP_TRY(c, lass_launch_weights_bf16(w1, rb.cout, rb.cin, 9, t1, st));
-            HIP_TRY(c, lass_launch_weights_bf16(w2, rb.cout, rb.cout, 9, t2, st));
+            HIP_TRY(c, lass_launch_weights_bf16(w1, rb.cout, rb.cin, 9, t1, 0, st));
+            HIP_TRY(c, lass_launch_weights_bf16(w2, rb.cout, rb.cout, 9, t2, 0, st));
             rb.b1 = t1; rb.b2 = t2;
+            if (split) {
+                unsigned short *l1 = nullptr, *l2 = nullptr;
+                if (dev_alloc(c, &l1, (size_t)rb.cout * rb.cin * 9) || dev_alloc(c, &l2, (size_t)rb.cout * rb.cout * 9))
+                    return LASS_ERR_HIP;
+                HIP_TRY(c, lass_launch_weights_bf16(w1, rb.cout, rb.cin, 9, l1, 1, st));
+                HIP_TRY(c, lass_launch_weights_bf16(w2, rb.cout, rb.cout, 9, l2, 1, st));
+                rb.b1l = l1; rb.b2l = l2;
+            }
         }
         if (c->wino && c->compute_mode == LASS_COMPUTE_F32) {
             if (dev_alloc(c, &rb.u1, (size_t)16 * rb.cout * rb.cin) || dev_alloc(c, &rb.u2, (size_t)16 * rb.cout * rb.cout))
@@ -602,11 +613,17 @@ int lass_finalize(lass_ctx* c, int compute_mode) {
             if (dev_alloc(c, &rb.wsc, (size_t)rb.cout * rb.cin)) return LASS_ERR_HIP;
             HIP_TRY(c, lass_launch_relayout_conv(ws, rb.cout, rb.cin, 1, rb.wsc, st));
             rb.bsc = bs;
-            if (c->compute_mode == LASS_COMPUTE_BF16 && rb.b1) {
+            if (bfm && rb.b1) {
                 unsigned short* t3 = nullptr;
                 if (dev_alloc(c, &t3, (size_t)rb.cout * rb.cin)) return LASS_ERR_HIP;
-                HIP_TRY(c, lass_launch_weights_bf16(ws, rb.cout, rb.cin, 1, t3, st));
+                HIP_TRY(c, lass_launch_weights_bf16(ws, rb.cout, rb.cin, 1, t3, 0, st));
                 rb.bsc16 = t3;
+                if (split) {
+                    unsigned short* l3 = nullptr;
+                    if (dev_alloc(c, &l3, (size_t)rb.cout * rb.cin)) return LASS_ERR_HIP;
+                    HIP_TRY(c, lass_launch_weights_bf16(ws, rb.cout, rb.cin, 1, l3, 1, st));
+                    rb.bscl = l3;
+                }
             }
             if (c->wino && c->compute_mode == LASS_COMPUTE_F32) {
                 if (dev_alloc(c, &rb.usc, (size_t)4 * rb.cout * rb.cin)) return LASS_ERR_HIP;

@@ -20,7 +20,9 @@ namespace {
 
 constexpr int KB = 16;  // input channels per chunk
 
-template <int TAPS, int NCO, int NPX, int PW, bool PRO>
+// SPLIT = 1: operands rounded to bf16.  SPLIT = 2: every f32 operand is split x = hi + lo (two bf16) and the product is
+// formed as hi*hi + hi*lo + lo*hi (three MFMAs, f32 accumulate): ~16 mantissa bits per operand, error ~2^-17 per product.
+template <int TAPS, int NCO, int NPX, int PW, bool PRO, int SPLIT>
 struct Phase16 {
     static constexpr int PH = 32 / PW;
     static constexpr int WROWS = NPX * PH;
@@ -31,15 +33,17 @@ struct Phase16 {
     static constexpr int NT = 32 * NCO;
     static constexpr int NPIX = IR * IP;
     static constexpr int NPP = (NPIX + NTHREADS - 1) / NTHREADS;  // pixel passes (each thread: one pixel, 8 channels)
-    static constexpr int IN_U4 = 2 * NPIX;                        // 16-byte units
-    static constexpr int W_U4 = TAPS * 2 * NT;
-    static constexpr int NWLD = (W_U4 + NTHREADS - 1) / NTHREADS;
+    static constexpr int IN1_U4 = 2 * NPIX;                       // 16-byte units, one plane (hi or lo)
+    static constexpr int W1_U4 = TAPS * 2 * NT;
+    static constexpr int IN_U4 = SPLIT * IN1_U4;
+    static constexpr int W_U4 = SPLIT * W1_U4;
+    static constexpr int NWLD = (W1_U4 + NTHREADS - 1) / NTHREADS;
     static constexpr int LDS_U4 = IN_U4 + W_U4;
 
     int goff[NPP];
     unsigned okbits;
     float v[2][NPP][8];  // prefetched f32 activations: [octet][pass][channel in octet]
-    uint4 wv[NWLD];      // prefetched bf16 weights
+    uint4 wv[SPLIT][NWLD];  // prefetched bf16 weights (hi, lo)
     float psc[KB], psh[KB];
 
     __device__ __forceinline__ static int upos(int tid, int k) {
@@ -60,8 +64,8 @@ struct Phase16 {
     }
     // in_c0: channel c0 of this clip (f32 planes); wb: this chunk's weight slab [tap][octet][Cout] in 16-B units, + n0
     __device__ __forceinline__ void load(const float* __restrict__ in_c0, int HW, const uint4* __restrict__ wb,
-                                         int Cout, const float* __restrict__ sc, const float* __restrict__ sh,
-                                         int tid) {
+                                         const uint4* __restrict__ wb_lo, int Cout, const float* __restrict__ sc,
+                                         const float* __restrict__ sh, int tid) {
 #pragma unroll
         for (int o = 0; o < 2; ++o)
 #pragma unroll
@@ -71,9 +75,10 @@ struct Phase16 {
 #pragma unroll
         for (int i = 0; i < NWLD; ++i) {
             const int e0 = tid + i * NTHREADS;
-            const int e = e0 < W_U4 ? e0 : W_U4 - 1;
+            const int e = e0 < W1_U4 ? e0 : W1_U4 - 1;
             const int row = e / NT, col = e % NT;  // row = tap*2 + octet
-            wv[i] = wb[(size_t)row * Cout + col];
+            wv[0][i] = wb[(size_t)row * Cout + col];
+            if (SPLIT == 2) wv[1][i] = wb_lo[(size_t)row * Cout + col];
         }
         if (PRO) {
 #pragma unroll
@@ -90,19 +95,24 @@ struct Phase16 {
             for (int k = 0; k < NPP; ++k) {
                 const int u = upos(tid, k);
                 const bool ok = (okbits >> k) & 1u;
-                bf16x8 pk;
+                bf16x8 pk, pl;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     float t = v[o][k][j];
                     if (PRO) t = leaky(t * psc[o * 8 + j] + psh[o * 8 + j]);
-                    pk[j] = (__bf16)(ok ? t : 0.f);  // conv zero padding comes after the activation
+                    t = ok ? t : 0.f;  // conv zero padding comes after the activation
+                    pk[j] = (__bf16)t;
+                    if (SPLIT == 2) pl[j] = (__bf16)(t - (float)pk[j]);
                 }
                 *reinterpret_cast<bf16x8*>(lds + o * NPIX + u) = pk;
+                if (SPLIT == 2) *reinterpret_cast<bf16x8*>(lds + IN1_U4 + o * NPIX + u) = pl;
             }
 #pragma unroll
         for (int i = 0; i < NWLD; ++i) {
             const int e0 = tid + i * NTHREADS;
-            lds[IN_U4 + (e0 < W_U4 ? e0 : W_U4 - 1)] = wv[i];
+            const int e = e0 < W1_U4 ? e0 : W1_U4 - 1;
+            lds[IN_U4 + e] = wv[0][i];
+            if (SPLIT == 2) lds[IN_U4 + W1_U4 + e] = wv[1][i];
         }
     }
     __device__ __forceinline__ static void compute(const uint4* lds, f32x16 (&acc)[NCO][NPX], int lane, int wave) {
@@ -110,6 +120,32 @@ struct Phase16 {
         const int ty = j / PW, tx = j % PW;
         const bf16x8* bbase = reinterpret_cast<const bf16x8*>(lds) + h * NPIX + (wave * WROWS + ty) * IP + tx;
         const bf16x8* abase = reinterpret_cast<const bf16x8*>(lds) + IN_U4 + h * NT + j;
+        if (SPLIT == 2) {
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap) {
+                bf16x8 ah[NCO], al[NCO], bh[NPX], bl[NPX];
+#pragma unroll
+                for (int co = 0; co < NCO; ++co) {
+                    ah[co] = abase[tap * 2 * NT + co * 32];
+                    al[co] = abase[W1_U4 + tap * 2 * NT + co * 32];
+                }
+#pragma unroll
+                for (int px = 0; px < NPX; ++px) {
+                    const int off = (px * PH + (TAPS == 9 ? tap / 3 : 0)) * IP + (TAPS == 9 ? tap % 3 : 0);
+                    bh[px] = bbase[off];
+                    bl[px] = bbase[IN1_U4 + off];
+                }
+#pragma unroll
+                for (int co = 0; co < NCO; ++co)
+#pragma unroll
+                    for (int px = 0; px < NPX; ++px) {  // small terms first
+                        acc[co][px] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[co], bh[px], acc[co][px], 0, 0, 0);
+                        acc[co][px] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[co], bl[px], acc[co][px], 0, 0, 0);
+                        acc[co][px] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[co], bh[px], acc[co][px], 0, 0, 0);
+                    }
+            }
+            return;
+        }
         bf16x8 a[2][NCO], b[2][NPX];
         auto rd = [&](int tap, bf16x8 (&aa)[NCO], bf16x8 (&bb)[NPX]) {
 #pragma unroll
@@ -139,7 +175,7 @@ struct MaxU {
     static constexpr int v = A > B ? A : B;
 };
 
-template <int NCO, int NPX, int PW, int FLAGS>
+template <int NCO, int NPX, int PW, int FLAGS, int SPLIT>
 __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
     constexpr bool PRO = (FLAGS & F_PRO) != 0;
     constexpr bool HASB = (FLAGS & F_PHASEB) != 0;
@@ -147,8 +183,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
     constexpr bool BIAS = (FLAGS & F_BIAS) != 0;
     constexpr bool RES = (FLAGS & F_RES) != 0;
     constexpr bool RES_PF = RES && NCO == 1;
-    using PA = Phase16<9, NCO, NPX, PW, PRO>;
-    using PB = Phase16<1, NCO, NPX, PW, false>;
+    using PA = Phase16<9, NCO, NPX, PW, PRO, SPLIT>;
+    using PB = Phase16<1, NCO, NPX, PW, false, SPLIT>;
     constexpr int LDS_U4 = HASB ? MaxU<PA::LDS_U4, PB::LDS_U4>::v : PA::LDS_U4;
     constexpr int PH = PA::PH, WROWS = PA::WROWS, PHT = PA::PHT, NT = PA::NT;
     constexpr int NTAB = (EPI ? 2 * NT : 0) + (BIAS ? NT : 0);
@@ -177,6 +213,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
     const float* sh = PRO ? p.pro_shift + (size_t)b * p.pro_shift_bs : nullptr;
     const uint4* wa = reinterpret_cast<const uint4*>(p.w_bf16) + n0;    // [chunk][tap][octet][Cout] 16-B units
     const uint4* wb2 = HASB ? reinterpret_cast<const uint4*>(p.w2_bf16) + n0 : nullptr;
+    const uint4* wa_lo = SPLIT == 2 ? reinterpret_cast<const uint4*>(p.w_bf16_lo) + n0 : nullptr;
+    const uint4* wb2_lo = (HASB && SPLIT == 2) ? reinterpret_cast<const uint4*>(p.w2_bf16_lo) + n0 : nullptr;
 
     if (EPI && tid < NT) {
         lds_es[tid] = p.epi_scale[n0 + tid];
@@ -187,10 +225,12 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
     PA pa;
     PB pb;
     auto loadA = [&](int c) {
-        pa.load(in_b + (size_t)c * KB * HW, HW, wa + (size_t)c * 9 * 2 * p.Nw, p.Nw, sc + c * KB, sh + c * KB, tid);
+        pa.load(in_b + (size_t)c * KB * HW, HW, wa + (size_t)c * 9 * 2 * p.Nw, wa_lo + (size_t)c * 9 * 2 * p.Nw, p.Nw,
+                sc + c * KB, sh + c * KB, tid);
     };
     auto loadB = [&](int c) {
-        pb.load(in2_b + (size_t)c * KB * HW, HW, wb2 + (size_t)c * 2 * p.Nw, p.Nw, nullptr, nullptr, tid);
+        pb.load(in2_b + (size_t)c * KB * HW, HW, wb2 + (size_t)c * 2 * p.Nw, wb2_lo + (size_t)c * 2 * p.Nw, p.Nw, nullptr,
+                nullptr, tid);
     };
 
     pa.init(tid, y0, x0, p.H, p.W);
@@ -247,8 +287,9 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
 }
 
 // dst[chunk][tap][octet][Cout][8] (bf16, RNE) = src[co][ci = chunk*16 + octet*8 + j][tap]   (taps = 9 or 1)
+// lo != 0: dst = bf16(w - float(bf16(w))), the second term of the hi + lo split
 __global__ __launch_bounds__(256) void weights_bf16_kernel(const float* __restrict__ src, int Cout, int Cin, int taps,
-                                                           __bf16* __restrict__ dst) {
+                                                           __bf16* __restrict__ dst, int lo) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     const long n = (long)Cout * Cin * taps;
     if (i >= n) return;
@@ -258,17 +299,26 @@ __global__ __launch_bounds__(256) void weights_bf16_kernel(const float* __restri
     const int tap = (int)((i / (16L * Cout)) % taps);
     const int chunk = (int)(i / (16L * Cout * taps));
     const int ci = chunk * 16 + o * 8 + jj;
-    dst[i] = (__bf16)src[((size_t)co * Cin + ci) * taps + tap];
+    const float w = src[((size_t)co * Cin + ci) * taps + tap];
+    const __bf16 hi = (__bf16)w;
+    dst[i] = lo ? (__bf16)(w - (float)hi) : hi;
 }
 
 template <int FLAGS>
 hipError_t launch_bf16(const ConvArgs& p, hipStream_t stream) {
+    const bool split = p.w_bf16_lo != nullptr;
     if (p.N % 64 == 0) {
         dim3 grid((p.W / 32) * ((p.H + 7) / 8), p.N / 64, p.B);
-        hipLaunchKernelGGL((conv_bf16_kernel<2, 2, 32, FLAGS>), grid, dim3(NTHREADS), 0, stream, p);
+        if (split)
+            hipLaunchKernelGGL((conv_bf16_kernel<2, 2, 32, FLAGS, 2>), grid, dim3(NTHREADS), 0, stream, p);
+        else
+            hipLaunchKernelGGL((conv_bf16_kernel<2, 2, 32, FLAGS, 1>), grid, dim3(NTHREADS), 0, stream, p);
     } else {
         dim3 grid((p.W / 32) * ((p.H + 7) / 8), p.N / 32, p.B);
-        hipLaunchKernelGGL((conv_bf16_kernel<1, 2, 32, FLAGS>), grid, dim3(NTHREADS), 0, stream, p);
+        if (split)
+            hipLaunchKernelGGL((conv_bf16_kernel<1, 2, 32, FLAGS, 2>), grid, dim3(NTHREADS), 0, stream, p);
+        else
+            hipLaunchKernelGGL((conv_bf16_kernel<1, 2, 32, FLAGS, 1>), grid, dim3(NTHREADS), 0, stream, p);
     }
     return hipGetLastError();
 }
@@ -289,16 +339,18 @@ hipError_t lass_launch_conv_bf16(ConvKind kind, const ConvArgs& p, hipStream_t s
             if (!p.res) return hipErrorInvalidValue;
             return launch_bf16<F_RES>(p, stream);
         case CONV2_SHORTCUT:
-            if (!p.in2 || !p.w2_bf16 || !p.bias || p.Cin2 % 16 != 0) return hipErrorInvalidValue;
+            if (!p.in2 || !p.w2_bf16 || !p.bias || p.Cin2 % 16 != 0 || (p.w_bf16_lo && !p.w2_bf16_lo))
+                return hipErrorInvalidValue;
             return launch_bf16<F_PHASEB | F_BIAS>(p, stream);
         default:
             return hipErrorInvalidValue;
     }
 }
 
-hipError_t lass_launch_weights_bf16(const float* w, int Cout, int Cin, int taps, void* dst, hipStream_t stream) {
+hipError_t lass_launch_weights_bf16(const float* w, int Cout, int Cin, int taps, void* dst, int lo,
+                                    hipStream_t stream) {
     const long n = (long)Cout * Cin * taps;
     hipLaunchKernelGGL(weights_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, w, Cout, Cin, taps,
-                       (__bf16*)dst);
+                       (__bf16*)dst, lo);
     return hipGetLastError();
 }

@@ -41,6 +41,8 @@ struct ConvArgs {
     const float* w2_wino = nullptr;  // Winograd-domain shortcut weights [4][Cin2][Nw]
     const void* w_bf16 = nullptr;    // bf16 weights [Cin/16][tap][2][Nw][8] (conv_bf16.hip)
     const void* w2_bf16 = nullptr;   // bf16 shortcut weights [Cin2/16][1][2][Nw][8]
+    const void* w_bf16_lo = nullptr;   // split mode: bf16(w - float(bf16(w))), same layouts; non-null selects the 3-MFMA kernels
+    const void* w2_bf16_lo = nullptr;
     const float* pre_w = nullptr;  // pre_conv (1x1, 1 -> 32) weight / bias for the *_PRE kinds
     const float* pre_b = nullptr;
     float* pool_out = nullptr;  // fused avg-pool of the output: (B, N, H/pool_h, W/2) dense
@@ -61,7 +63,7 @@ hipError_t lass_launch_wino_shortcut_weights(const float* w, int Cout, int Cin, 
 // ---- conv_bf16.hip (bf16-MFMA variant of the 3x3 kinds; W multiple of 32, Cin multiple of 16) ----------------------
 bool lass_bf16_supported(const ConvArgs& p);
 hipError_t lass_launch_conv_bf16(ConvKind kind, const ConvArgs& p, hipStream_t stream);
-hipError_t lass_launch_weights_bf16(const float* w, int Cout, int Cin, int taps, void* dst, hipStream_t stream);
+hipError_t lass_launch_weights_bf16(const float* w, int Cout, int Cin, int taps, void* dst, int lo, hipStream_t stream);
 
 // ---- stft.hip -----------------------------------------------------------------------------------------------------
 // tw: 1024 float2 (cos, sin)(2*pi*k/1024); win: 1024 floats (periodic Hann)

@@ -63,7 +63,7 @@ class Engine:
         self.finalized = False
         return _lib.check(self.ctx, rc, f"lass_set_param({name})")
 
-    COMPUTE_MODES = {"f32": 0, "bf16": 1}  # include/lass_hip.h: LASS_COMPUTE_F32 / LASS_COMPUTE_BF16
+    COMPUTE_MODES = {"f32": 0, "bf16": 1, "bf16x3": 2}  # include/lass_hip.h: LASS_COMPUTE_*
 
     def load_state_dict(self, sd: Dict[str, object], compute_dtype: str = "f32"):
         for k, v in sd.items():

@@ -355,3 +355,20 @@ def test_bf16_mode_convblock_and_waveform(synthetic_sd, oracle_sd):
     rel = _relerr(out, ref)
     print("bf16 waveform relative RMS error", rel)
     assert rel < 5e-2, rel
+
+
+def test_bf16x3_split_mode_is_f32_accurate(synthetic_sd, oracle_sd, golden_dir):
+    """LASS_COMPUTE_BF16X3: operands split hi+lo (two bf16), products hi*hi + hi*lo + lo*hi on the bf16 MFMA with f32
+    accumulation.  ~16 mantissa bits per operand: must stay within the f32 path's own tolerance class (bar 1e-4)."""
+    from lass_amd.resunet import ResUNet30
+    from oracle import resunet as orr
+    m = ResUNet30(1, 1, 512)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synthetic_sd.items()})
+    m = m.to(DEV).eval().set_compute_dtype("bf16x3")
+    _, mix = synthetic.make_mixtures(2, 16000)
+    c2 = synthetic.make_condition(2)
+    out = m({"mixture": torch.from_numpy(mix)[:, None, :].to(DEV), "condition": torch.from_numpy(c2).to(DEV)})["waveform"]
+    g = np.load(os.path.join(golden_dir, "g1_tiny.npz"))
+    err = _rms(out.cpu() - torch.from_numpy(g["waveform"]))
+    print("bf16x3 waveform RMS error vs the reference's own output", err, "relative", err / _rms(g["waveform"]))
+    assert err < 1e-5, err
