@@ -168,6 +168,8 @@ def main():
                 exec_flops += 2.0 * B * r["macs"]
         executed = exec_flops / (per_step_ms * 1e-3) / 1e12 if per_step_ms > 0 else 0.0
         peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
+        conv_bytes = float(B) * arch.conv3x3_bytes_per_clip(L)
+        hbm_gbs = conv_bytes / (per_step_ms * 1e-3) / 1e9 if per_step_ms > 0 else 0.0
         res = {
             "metric": "clips/sec (10s@16kHz)", "value": world * B * args.steps / dt, "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -177,7 +179,7 @@ def main():
                                    f"seeded random-init weights (BASELINE configs[{1 if args.dtype == 'f32' else 2}])",
                        "clips_per_gpu_per_step": B, "samples_per_clip": L, "parallelism": f"clip-sharded x{world}"},
             "realtime_factor": world * B * args.steps / dt * (L / 16000.0),
-            "roofline": {"bound": "mfma", "kernel": "conv3x3_mfma (3x3 convs + fused 1x1 shortcuts, f32 MFMA; achieved = algorithmic direct-conv FLOPs)",
+            "roofline": {"bound": "mfma" if args.dtype == "f32" else "mfma (bf16) / hbm - see hbm_* fields", "kernel": "conv3x3_mfma (3x3 convs + fused 1x1 shortcuts, f32 MFMA; achieved = algorithmic direct-conv FLOPs)",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic if args.dtype == "f32" else None,
                          "traffic_meta": traffic_meta,
@@ -186,6 +188,7 @@ def main():
                                       ("Winograd F(2x2,3x3) on f32 MFMA for W>=32, direct below" if wino else "direct"),
                          "executed_tflops": executed if args.dtype == "f32" else achieved,
                          "executed_frac": (executed if args.dtype == "f32" else achieved) / peak,
+                         "hbm_algorithmic_gbs": hbm_gbs, "hbm_peak_gbs": PEAK_HBM_GBS, "hbm_frac": hbm_gbs / PEAK_HBM_GBS,
                          "launches_per_step": launches / args.steps, "avg_launch_ms": ms / max(1, launches),
                          "algorithmic_gflop_per_step": conv_flops / 1e9,
                          "whole_step_tflops": total_flops / (dt / args.steps) / 1e12},

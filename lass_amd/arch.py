@@ -174,3 +174,27 @@ def conv_layer_table(t_pad: int, f: int = F_CROP) -> List[Dict]:
 
 def conv_macs_per_clip(length: int) -> int:
     return sum(r["macs"] for r in conv_layer_table(padded_frames(frames_for(length))))
+
+
+def conv3x3_bytes_per_clip(length: int, bytes_per_elem: int = 4) -> int:
+    """Compulsory HBM bytes of the 26 conv3x3-class launches per clip with ideal per-launch fusion (every launch reads
+    its input(s) once and writes its output(s) once; f32 storage): conv1 reads the block input, writes the activated
+    intermediate; conv2 reads it, re-reads the block input for the residual / 1x1 shortcut, writes the block output and
+    (encoders 1-6) the pooled output.  encoder_block1 reads the 1-channel x0 instead of a materialised pre_conv."""
+    tp = padded_frames(frames_for(length))
+    h, w = tp, F_CROP
+    elems = 0
+    for i, e in enumerate(ENCODERS):
+        hw = h * w
+        cin_read = 1 if i == 0 else e.cin
+        elems += cin_read * hw + e.cout * hw            # conv1
+        elems += e.cout * hw + cin_read * hw + e.cout * hw  # conv2 (+ residual / shortcut input)
+        if i < 6:
+            elems += e.cout * (h // e.down[0]) * (w // e.down[1])
+        h, w = h // e.down[0], w // e.down[1]
+    for d in DECODERS:
+        h, w = h * d.up[0], w * d.up[1]
+        hw = h * w
+        elems += 2 * d.cout * hw + d.cout * hw            # conv1 over the concat
+        elems += d.cout * hw + 2 * d.cout * hw + d.cout * hw  # conv2 + shortcut over the concat
+    return elems * bytes_per_elem

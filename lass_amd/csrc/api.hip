@@ -79,6 +79,8 @@ struct lass_ctx {
     float *bn0_s = nullptr, *bn0_h = nullptr;
     std::vector<ResBlock> enc, dec;  // 7 + 6
     int dec_site[6] = {0};           // decoder_blockN->beta1
+    void* up16[6] = {nullptr};       // bf16 transposed-conv weights (hi) per decoder, bf16 modes only
+    void* up16l[6] = {nullptr};      // lo halves (LASS_COMPUTE_BF16X3)
     std::vector<void*> owned;        // derived device buffers to free
     // profiling
     int compute_mode = LASS_COMPUTE_F32;
@@ -361,8 +363,12 @@ int run_upconv(lass_ctx* c, int di, const float* x, int B, int h, int w, const f
     p.N = p.Nw = d.cout * d.uh * d.uw;
     p.pro_scale = c->bn_scale + s.off; p.pro_shift = shift + s.off; p.pro_shift_bs = c->n_shift;
     p.out = out; p.out_bs = out_bs; p.B = B; p.H = h; p.W = w; p.up_h = d.uh;
+    p.w_bf16 = c->up16[di]; p.w_bf16_lo = c->up16l[di];
     ProfScope ps(c, st, P_TCONV);
-    HIP_TRY(c, lass_launch_conv(TCONV_ACT, p, st));
+    if (c->compute_mode != LASS_COMPUTE_F32 && p.w_bf16 && lass_bf16_supported(p))
+        HIP_TRY(c, lass_launch_conv_bf16(TCONV_ACT, p, st));
+    else
+        HIP_TRY(c, lass_launch_conv(TCONV_ACT, p, st));
     return 0;
 }
 
@@ -587,15 +593,15 @@ int lass_finalize(lass_ctx* c, int compute_mode) {
             unsigned short *t1 = nullptr, *t2 = nullptr;
             if (dev_alloc(c, &t1, (size_t)rb.cout * rb.cin * 9) || dev_alloc(c, &t2, (size_t)rb.cout * rb.cout * 9))
                 return LASS_ERR_HIP;
-            HIP_TRY(c, lass_launch_weights_bf16(w1, rb.cout, rb.cin, 9, t1, 0, st));
-            HIP_TRY(c, lass_launch_weights_bf16(w2, rb.cout, rb.cout, 9, t2, 0, st));
+            HIP_TRY(c, lass_launch_weights_bf16(w1, rb.cout, rb.cin, 9, t1, 0, 0, st));
+            HIP_TRY(c, lass_launch_weights_bf16(w2, rb.cout, rb.cout, 9, t2, 0, 0, st));
             rb.b1 = t1; rb.b2 = t2;
             if (split) {
                 unsigned short *l1 = nullptr, *l2 = nullptr;
                 if (dev_alloc(c, &l1, (size_t)rb.cout * rb.cin * 9) || dev_alloc(c, &l2, (size_t)rb.cout * rb.cout * 9))
                     return LASS_ERR_HIP;
-                HIP_TRY(c, lass_launch_weights_bf16(w1, rb.cout, rb.cin, 9, l1, 1, st));
-                HIP_TRY(c, lass_launch_weights_bf16(w2, rb.cout, rb.cout, 9, l2, 1, st));
+                HIP_TRY(c, lass_launch_weights_bf16(w1, rb.cout, rb.cin, 9, l1, 1, 0, st));
+                HIP_TRY(c, lass_launch_weights_bf16(w2, rb.cout, rb.cout, 9, l2, 1, 0, st));
                 rb.b1l = l1; rb.b2l = l2;
             }
         }
@@ -616,12 +622,12 @@ int lass_finalize(lass_ctx* c, int compute_mode) {
             if (bfm && rb.b1) {
                 unsigned short* t3 = nullptr;
                 if (dev_alloc(c, &t3, (size_t)rb.cout * rb.cin)) return LASS_ERR_HIP;
-                HIP_TRY(c, lass_launch_weights_bf16(ws, rb.cout, rb.cin, 1, t3, 0, st));
+                HIP_TRY(c, lass_launch_weights_bf16(ws, rb.cout, rb.cin, 1, t3, 0, 0, st));
                 rb.bsc16 = t3;
                 if (split) {
                     unsigned short* l3 = nullptr;
                     if (dev_alloc(c, &l3, (size_t)rb.cout * rb.cin)) return LASS_ERR_HIP;
-                    HIP_TRY(c, lass_launch_weights_bf16(ws, rb.cout, rb.cin, 1, l3, 1, st));
+                    HIP_TRY(c, lass_launch_weights_bf16(ws, rb.cout, rb.cin, 1, l3, 1, 0, st));
                     rb.bscl = l3;
                 }
             }
@@ -634,8 +640,24 @@ int lass_finalize(lass_ctx* c, int compute_mode) {
     };
     for (auto& rb : c->enc) { int r = prep(rb); if (r) return r; }
     for (auto& rb : c->dec) { int r = prep(rb); if (r) return r; }
-    for (const auto& d : kDec)
-        if (!need(std::string("base.") + d.name + ".conv1.weight")) return LASS_ERR_STATE;
+    for (int i = 0; i < 6; ++i) {
+        const auto& d = kDec[i];
+        const float* wu = need(std::string("base.") + d.name + ".conv1.weight");
+        if (!wu) return LASS_ERR_STATE;
+        c->up16[i] = c->up16l[i] = nullptr;
+        if (c->compute_mode != LASS_COMPUTE_F32 && d.cin % 16 == 0) {
+            const int N = d.cout * d.uh * d.uw;
+            unsigned short *t = nullptr, *l = nullptr;
+            if (dev_alloc(c, &t, (size_t)N * d.cin)) return LASS_ERR_HIP;
+            HIP_TRY(c, lass_launch_weights_bf16(wu, N, d.cin, 1, t, 0, 1, st));
+            c->up16[i] = t;
+            if (c->compute_mode == LASS_COMPUTE_BF16X3) {
+                if (dev_alloc(c, &l, (size_t)N * d.cin)) return LASS_ERR_HIP;
+                HIP_TRY(c, lass_launch_weights_bf16(wu, N, d.cin, 1, l, 1, 1, st));
+                c->up16l[i] = l;
+            }
+        }
+    }
     HIP_TRY(c, hipStreamSynchronize(st));
     c->finalized = true;
     return 0;

@@ -175,7 +175,7 @@ struct MaxU {
     static constexpr int v = A > B ? A : B;
 };
 
-template <int NCO, int NPX, int PW, int FLAGS, int SPLIT>
+template <int TAPS, int NCO, int NPX, int PW, int FLAGS, int SPLIT>
 __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
     constexpr bool PRO = (FLAGS & F_PRO) != 0;
     constexpr bool HASB = (FLAGS & F_PHASEB) != 0;
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
     constexpr bool BIAS = (FLAGS & F_BIAS) != 0;
     constexpr bool RES = (FLAGS & F_RES) != 0;
     constexpr bool RES_PF = RES && NCO == 1;
-    using PA = Phase16<9, NCO, NPX, PW, PRO, SPLIT>;
+    using PA = Phase16<TAPS, NCO, NPX, PW, PRO, SPLIT>;
     using PB = Phase16<1, NCO, NPX, PW, false, SPLIT>;
     constexpr int LDS_U4 = HASB ? MaxU<PA::LDS_U4, PB::LDS_U4>::v : PA::LDS_U4;
     constexpr int PH = PA::PH, WROWS = PA::WROWS, PHT = PA::PHT, NT = PA::NT;
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
     PA pa;
     PB pb;
     auto loadA = [&](int c) {
-        pa.load(in_b + (size_t)c * KB * HW, HW, wa + (size_t)c * 9 * 2 * p.Nw, wa_lo + (size_t)c * 9 * 2 * p.Nw, p.Nw,
+        pa.load(in_b + (size_t)c * KB * HW, HW, wa + (size_t)c * TAPS * 2 * p.Nw, wa_lo + (size_t)c * TAPS * 2 * p.Nw, p.Nw,
                 sc + c * KB, sh + c * KB, tid);
     };
     auto loadB = [&](int c) {
@@ -283,13 +283,16 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
         }
         PB::compute(lds4, acc, lane, wave);
     }
-    store_tile<NCO, NPX, PW, FLAGS, RES_PF>(p, acc, rtmp, lds_es, lds_eh, b, n0, y0, x0, lane, wave);
+    if (FLAGS & F_TCONV)
+        tconv_store<NCO, NPX, PW>(p, acc, b, n0, y0, x0, lane, wave);
+    else
+        store_tile<NCO, NPX, PW, FLAGS, RES_PF>(p, acc, rtmp, lds_es, lds_eh, b, n0, y0, x0, lane, wave);
 }
 
 // dst[chunk][tap][octet][Cout][8] (bf16, RNE) = src[co][ci = chunk*16 + octet*8 + j][tap]   (taps = 9 or 1)
 // lo != 0: dst = bf16(w - float(bf16(w))), the second term of the hi + lo split
 __global__ __launch_bounds__(256) void weights_bf16_kernel(const float* __restrict__ src, int Cout, int Cin, int taps,
-                                                           __bf16* __restrict__ dst, int lo) {
+                                                           __bf16* __restrict__ dst, int lo, int transposed) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     const long n = (long)Cout * Cin * taps;
     if (i >= n) return;
@@ -299,34 +302,40 @@ __global__ __launch_bounds__(256) void weights_bf16_kernel(const float* __restri
     const int tap = (int)((i / (16L * Cout)) % taps);
     const int chunk = (int)(i / (16L * Cout * taps));
     const int ci = chunk * 16 + o * 8 + jj;
-    const float w = src[((size_t)co * Cin + ci) * taps + tap];
+    // transposed (taps == 1): src is [Cin][Cout] - the ConvTranspose2d weight (cin, cout, kh, kw) with n = (cout, kh, kw)
+    const float w = transposed ? src[(size_t)ci * Cout + co] : src[((size_t)co * Cin + ci) * taps + tap];
     const __bf16 hi = (__bf16)w;
     dst[i] = lo ? (__bf16)(w - (float)hi) : hi;
 }
 
-template <int FLAGS>
-hipError_t launch_bf16(const ConvArgs& p, hipStream_t stream) {
-    const bool split = p.w_bf16_lo != nullptr;
-    if (p.N % 64 == 0) {
-        dim3 grid((p.W / 32) * ((p.H + 7) / 8), p.N / 64, p.B);
-        if (split)
-            hipLaunchKernelGGL((conv_bf16_kernel<2, 2, 32, FLAGS, 2>), grid, dim3(NTHREADS), 0, stream, p);
-        else
-            hipLaunchKernelGGL((conv_bf16_kernel<2, 2, 32, FLAGS, 1>), grid, dim3(NTHREADS), 0, stream, p);
-    } else {
-        dim3 grid((p.W / 32) * ((p.H + 7) / 8), p.N / 32, p.B);
-        if (split)
-            hipLaunchKernelGGL((conv_bf16_kernel<1, 2, 32, FLAGS, 2>), grid, dim3(NTHREADS), 0, stream, p);
-        else
-            hipLaunchKernelGGL((conv_bf16_kernel<1, 2, 32, FLAGS, 1>), grid, dim3(NTHREADS), 0, stream, p);
-    }
+template <int TAPS, int NCO, int NPX, int PW, int FLAGS>
+hipError_t launch_bf16_one(const ConvArgs& p, hipStream_t stream) {
+    constexpr int PHT = 4 * NPX * (32 / PW);
+    dim3 grid((p.W / PW) * ((p.H + PHT - 1) / PHT), p.N / (32 * NCO), p.B);
+    if (p.w_bf16_lo)
+        hipLaunchKernelGGL((conv_bf16_kernel<TAPS, NCO, NPX, PW, FLAGS, 2>), grid, dim3(NTHREADS), 0, stream, p);
+    else
+        hipLaunchKernelGGL((conv_bf16_kernel<TAPS, NCO, NPX, PW, FLAGS, 1>), grid, dim3(NTHREADS), 0, stream, p);
     return hipGetLastError();
+}
+
+// Tile geometry as in conv.hip: 64-cout tiles at W >= 32, small tiles at the bottom of the U-Net.
+template <int TAPS, int FLAGS>
+hipError_t launch_bf16(const ConvArgs& p, hipStream_t stream) {
+    const int pw = p.W >= 32 ? 32 : p.W;
+    if (pw == 32) {
+        if (p.N % 64 == 0) return launch_bf16_one<TAPS, 2, 2, 32, FLAGS>(p, stream);
+        return launch_bf16_one<TAPS, 1, 2, 32, FLAGS>(p, stream);
+    }
+    if (pw == 16) return launch_bf16_one<TAPS, 1, 1, 16, FLAGS>(p, stream);
+    if (pw == 8) return launch_bf16_one<TAPS, 1, 2, 8, FLAGS>(p, stream);
+    return hipErrorInvalidValue;
 }
 
 }  // namespace
 
 bool lass_bf16_supported(const ConvArgs& p) {
-    return p.W >= 32 && (p.W % 32) == 0 && p.Cin % 16 == 0 && p.N % 32 == 0;
+    return (p.W == 8 || p.W == 16 || (p.W % 32) == 0) && p.Cin % 16 == 0 && p.N % 32 == 0;
 }
 
 hipError_t lass_launch_conv_bf16(ConvKind kind, const ConvArgs& p, hipStream_t stream) {
@@ -334,23 +343,26 @@ hipError_t lass_launch_conv_bf16(ConvKind kind, const ConvArgs& p, hipStream_t s
     switch (kind) {
         case CONV1_ACT:
             if (!p.pro_scale || !p.pro_shift || !p.epi_scale || !p.epi_shift) return hipErrorInvalidValue;
-            return launch_bf16<F_PRO | F_EPIACT>(p, stream);
+            return launch_bf16<9, F_PRO | F_EPIACT>(p, stream);
         case CONV2_IDENT:
             if (!p.res) return hipErrorInvalidValue;
-            return launch_bf16<F_RES>(p, stream);
+            return launch_bf16<9, F_RES>(p, stream);
         case CONV2_SHORTCUT:
             if (!p.in2 || !p.w2_bf16 || !p.bias || p.Cin2 % 16 != 0 || (p.w_bf16_lo && !p.w2_bf16_lo))
                 return hipErrorInvalidValue;
-            return launch_bf16<F_PHASEB | F_BIAS>(p, stream);
+            return launch_bf16<9, F_PHASEB | F_BIAS>(p, stream);
+        case TCONV_ACT:
+            if (!p.pro_scale || !p.pro_shift || (p.up_h != 1 && p.up_h != 2)) return hipErrorInvalidValue;
+            return launch_bf16<1, F_PRO | F_TCONV>(p, stream);
         default:
             return hipErrorInvalidValue;
     }
 }
 
-hipError_t lass_launch_weights_bf16(const float* w, int Cout, int Cin, int taps, void* dst, int lo,
+hipError_t lass_launch_weights_bf16(const float* w, int Cout, int Cin, int taps, void* dst, int lo, int transposed,
                                     hipStream_t stream) {
     const long n = (long)Cout * Cin * taps;
     hipLaunchKernelGGL(weights_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, w, Cout, Cin, taps,
-                       (__bf16*)dst, lo);
+                       (__bf16*)dst, lo, transposed);
     return hipGetLastError();
 }

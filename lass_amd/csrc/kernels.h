@@ -63,7 +63,8 @@ hipError_t lass_launch_wino_shortcut_weights(const float* w, int Cout, int Cin, 
 // ---- conv_bf16.hip (bf16-MFMA variant of the 3x3 kinds; W multiple of 32, Cin multiple of 16) ----------------------
 bool lass_bf16_supported(const ConvArgs& p);
 hipError_t lass_launch_conv_bf16(ConvKind kind, const ConvArgs& p, hipStream_t stream);
-hipError_t lass_launch_weights_bf16(const float* w, int Cout, int Cin, int taps, void* dst, int lo, hipStream_t stream);
+hipError_t lass_launch_weights_bf16(const float* w, int Cout, int Cin, int taps, void* dst, int lo, int transposed,
+                                    hipStream_t stream);
 
 // ---- stft.hip -----------------------------------------------------------------------------------------------------
 // tw: 1024 float2 (cos, sin)(2*pi*k/1024); win: 1024 floats (periodic Hann)
