@@ -179,12 +179,13 @@ def main():
                                    f"seeded random-init weights (BASELINE configs[{1 if args.dtype == 'f32' else 2}])",
                        "clips_per_gpu_per_step": B, "samples_per_clip": L, "parallelism": f"clip-sharded x{world}"},
             "realtime_factor": world * B * args.steps / dt * (L / 16000.0),
-            "roofline": {"bound": "mfma" if args.dtype == "f32" else "mfma (bf16) / hbm - see hbm_* fields", "kernel": "conv3x3_mfma (3x3 convs + fused 1x1 shortcuts, f32 MFMA; achieved = algorithmic direct-conv FLOPs)",
+            "roofline": {"bound": "mfma", "kernel": "conv3x3_mfma (3x3 convs + fused 1x1 shortcuts, f32 MFMA; achieved = algorithmic direct-conv FLOPs)",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic if args.dtype == "f32" else None,
                          "traffic_meta": traffic_meta,
-                         "algorithm": ("bf16 MFMA direct conv for W>=32 (staging-bound: f32 activations are converted while "
-                                       "staged), f32 direct below") if args.dtype == "bf16" else
+                         "algorithm": ("bf16 MFMA direct conv, f32 activations converted while staged"
+                                       + (" (hi+lo split operands, 3 MFMAs per product)" if args.dtype == "bf16x3" else ""))
+                                      if args.dtype != "f32" else
                                       ("Winograd F(2x2,3x3) on f32 MFMA for W>=32, direct below" if wino else "direct"),
                          "executed_tflops": executed if args.dtype == "f32" else achieved,
                          "executed_frac": (executed if args.dtype == "f32" else achieved) / peak,
