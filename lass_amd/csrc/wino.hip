@@ -21,8 +21,7 @@
 #include <type_traits>
 #include <vector>
 #include "kernels.h"
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+#include "wino_common.h"
 
 namespace {
 
@@ -31,6 +30,7 @@ constexpr int F_PRECONV = 64;   // input is the 1-channel x0; channel c = pre_w[
 constexpr int F_RESPRE = 128;   // with F_RES: the residual is pre_w[n]*x0 + pre_b[n]
 constexpr int NTHREADS = 256;
 constexpr int KC = 8;
+constexpr int KCB = 32;  // shortcut phase: 32 channels x 4 xi per chunk (the same 128 LDS rows and 64 MFMAs as a 3x3 chunk)
 constexpr int PWT = 16;  // Winograd tiles per row pair (32 output columns)
 
 __device__ __forceinline__ float leaky(float v) { return fmaxf(v, 0.01f * v); }
@@ -127,11 +127,11 @@ struct RawStage {
 // Uw[xi][Cin][Nw] into lu[row][NT] (row = xi_slot*KC + c).  One wave-instruction writes 1 KiB = RPI whole rows, lane-linear;
 // the bank swizzle (16-float halves of odd rows swapped, so the two k-rows a 32-lane group reads hit disjoint banks)
 // is therefore applied on the SOURCE address and undone by the fragment reader.
-template <int NXI, int NT>
+template <int NXI, int NT, int KCH = KC>
 struct UDma {
     static constexpr int RPI = 256 / NT;                 // rows per wave-instruction (4 or 8: never straddles a xi slot)
-    static constexpr int NINSTR = NXI * KC / RPI / 4;    // wave-instructions per wave
-    static_assert(NXI * KC % (RPI * 4) == 0 && KC % RPI == 0, "rows split evenly; an instruction stays in one xi slot");
+    static constexpr int NINSTR = NXI * KCH / RPI / 4;   // wave-instructions per wave
+    static_assert(NXI * KCH % (RPI * 4) == 0 && KCH % RPI == 0, "rows split evenly; an instruction stays in one xi slot");
     // Per-lane part of the source address (constant over chunks and instructions): row-in-instruction * Nw + swizzled col
     __device__ __forceinline__ static const float* lane_base(const float* Uw, int Nw, int n0, int lane) {
         const int rl = lane / (NT / 4);                  // row within the instruction's RPI rows
@@ -144,55 +144,12 @@ struct UDma {
 #pragma unroll
         for (int i = 0; i < NINSTR; ++i) {
             const int r0 = (wave * NINSTR + i) * RPI;    // wave-uniform
-            const int xi = r0 / KC, c = r0 % KC;
+            const int xi = r0 / KCH, c = r0 % KCH;
             const float* g = lane_ptr + ((size_t)xi * Cin + c0 + c) * Nw;
-            // Issued from inline asm so that hipcc does not know about the pending LDS write: with the builtin it
-            // drains vmcnt(0) in front of the next ds_read (the transform), exposing the DMA and the raw prefetch.
-            // Completion is tracked by hand (wait_vmcnt); M0 = wave-uniform LDS byte address of this 1-KiB piece.
-            const unsigned lds_addr = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(r0 * NT * 4));
-            unsigned keep;
-            asm volatile(
-                "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                : "=&s"(keep)
-                : "v"(g), "s"(lds_addr)
-                : "memory");
+            lds_dma_16B(g, lds_base + (unsigned)(r0 * NT * 4));  // M0 = wave-uniform LDS byte address of this 1-KiB piece
         }
     }
 };
-
-__device__ __forceinline__ void lds_barrier() {  // workgroup barrier that does NOT drain vmcnt (LDS-DMA stays in flight)
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {  // all but the N youngest vector-memory operations are complete
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-// S k-steps of 2 MFMAs; LDS row of step s = s*4 (+ lane>>4): rows are [xi-slot][channel] with KC/4 steps per slot.
-// The three fragment reads of step s+PFD are issued before the MFMAs of step s (pinned: hipcc sinks them otherwise and
-// then waits lgkmcnt(0) in front of every MFMA pair).
-template <int S, int UPITCH, int VPITCH, typename XiOf>
-__device__ __forceinline__ void gemm_steps(const float* afrag0, const float* afrag1, const float* bfrag,
-                                           f32x4 (&acc)[16][2], XiOf xi_of) {
-    constexpr int PFD = 3;
-    float bv[PFD + 1], a0[PFD + 1], a1[PFD + 1];
-    auto rd = [&](int s) {
-        bv[s % (PFD + 1)] = bfrag[(s * 4) * VPITCH];
-        a0[s % (PFD + 1)] = afrag0[(s * 4) * UPITCH];
-        a1[s % (PFD + 1)] = afrag1[(s * 4) * UPITCH];
-    };
-#pragma unroll
-    for (int s = 0; s < PFD && s < S; ++s) rd(s);
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-        if (s + PFD < S) rd(s + PFD);
-        __builtin_amdgcn_sched_barrier(0);
-        const int xi = xi_of(s);
-        acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s % (PFD + 1)], bv[s % (PFD + 1)], acc[xi][0], 0, 0, 0);
-        acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s % (PFD + 1)], bv[s % (PFD + 1)], acc[xi][1], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
 
 // WCO x WWT waves (product 4): block = 32*WCO couts x 16*WWT Winograd tiles = (2*WWT output rows) x 32 output cols.
 template <int WCO, int WWT, int FLAGS>
@@ -211,9 +168,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
     constexpr int IR = OR_ + 2, IP = OC + 2;
     constexpr int VP = NWT + 16;  // V row pitch (floats): spreads the 4 k-rows of a fragment read over the banks
     using RA = RawStage<IR, IP, 1, KC, PRO, PRE>;
-    using RB = RawStage<OR_, OC, 0, KC, false>;
     using UA = UDma<16, NT>;
-    using UB = UDma<4, NT>;
+    using UB = UDma<4, NT, KCB>;
     constexpr int RAW_F = KC * IR * IP;
     constexpr int V_F = 16 * KC * VP;
     constexpr int U_F = 16 * KC * NT;
@@ -372,55 +328,58 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
         }
     }
     // ---- shortcut phase: 1x1 over p.in2, in the transform domain (xi in {5,6,9,10}) -------------------------------
+    // Chunks of 32 channels: a thread owns one tile position and channels cb + i*CSTEP; it loads the 2x2 patch centres
+    // straight from global (two aligned 8-byte loads per item, issued one chunk ahead: they land during the MFMAs) and
+    // writes B^T d B to V - no raw tile, two barriers per 64 MFMAs.
     if (HASB) {
-        RB rb;
-        const float* in2_b = p.in2 + (size_t)b * p.in2_bs;
-        rb.init(tid, y0, x0, p.H, p.W);
-        const int nch = p.Cin2 / KC;  // even (host-checked)
-        rb.template load<0>(in2_b, HW);
-        rb.template load<1>(in2_b + (size_t)KC * HW, HW);
-        const float* ulane = UB::lane_base(p.w2_wino, p.Nw, n0, lane);
-        auto chunk = [&](int ch, auto buf) {
-            constexpr int BUF = decltype(buf)::value;
-            lds_barrier();
-            rb.template store<BUF>(lraw, nullptr, nullptr, tid);
-            __builtin_amdgcn_sched_barrier(0);
-            UB::issue(ulane, p.Cin2, p.Nw, ch * KC, lu_addr, wave);
-            __builtin_amdgcn_sched_barrier(0);
-            const bool pf = ch + 2 < nch;
-            if (pf) rb.template load<BUF>(in2_b + (size_t)(ch + 2) * KC * HW, HW);
-            __builtin_amdgcn_sched_barrier(0);
-            lds_barrier();
+        constexpr int CSTEP = NTHREADS / NWT;
+        constexpr int NITB = KCB / CSTEP;
+        const int wt = tid % NWT, cb = tid / NWT;
+        const int wty = wt / PWT, wtx = wt % PWT;
+        const int oy = y0 + 2 * wty, ox = x0 + 2 * wtx;
+        const bool okB = oy + 1 < p.H;
+        const float* in2_t = p.in2 + (size_t)b * p.in2_bs + (size_t)cb * HW + (size_t)min(oy, p.H - 2) * p.W + ox;
+        float2 rb[2 * NITB];
+        auto loadB = [&](int ch) {
+            const float* pc = in2_t + (size_t)ch * KCB * HW;
 #pragma unroll
-            for (int it = 0; it < (KC * NWT) / NTHREADS; ++it) {
-                const int item = tid + it * NTHREADS;
-                const int c = item / NWT, wt = item % NWT;
-                const int wty = wt / PWT, wtx = wt % PWT;
-                const float* src = lraw + c * (OR_ * OC) + (2 * wty) * OC + 2 * wtx;
-                const float2 r1 = *reinterpret_cast<const float2*>(src);       // patch rows 1,2 x cols 1,2
-                const float2 r2 = *reinterpret_cast<const float2*>(src + OC);
+            for (int it = 0; it < NITB; ++it) {
+                rb[2 * it] = *reinterpret_cast<const float2*>(pc + (size_t)it * CSTEP * HW);
+                rb[2 * it + 1] = *reinterpret_cast<const float2*>(pc + (size_t)it * CSTEP * HW + p.W);
+            }
+        };
+        const int nch = p.Cin2 / KCB;
+        loadB(0);
+        const float* ulane = UB::lane_base(p.w2_wino, p.Nw, n0, lane);
+        for (int ch = 0; ch < nch; ++ch) {
+            lds_barrier();  // previous chunk's MFMAs have finished reading V / U
+#pragma unroll
+            for (int it = 0; it < NITB; ++it) {
+                float2 r1 = rb[2 * it], r2 = rb[2 * it + 1];  // patch rows 1,2 x cols 1,2
+                if (!okB) { r1 = make_float2(0.f, 0.f); r2 = r1; }
                 const float t1a = r1.x + r2.x, t1b = r1.y + r2.y;  // tt[1][1], tt[1][2]
                 const float t2a = r2.x - r1.x, t2b = r2.y - r1.y;  // tt[2][1], tt[2][2]
-                float* dst = lv + c * VP + wt;
-                dst[0 * (KC * VP)] = t1a + t1b;  // V[1][1]
-                dst[1 * (KC * VP)] = t1b - t1a;  // V[1][2]
-                dst[2 * (KC * VP)] = t2a + t2b;  // V[2][1]
-                dst[3 * (KC * VP)] = t2b - t2a;  // V[2][2]
+                float* dst = lv + (cb + it * CSTEP) * VP + wt;
+                dst[0 * (KCB * VP)] = t1a + t1b;  // V[1][1]
+                dst[1 * (KCB * VP)] = t1b - t1a;  // V[1][2]
+                dst[2 * (KCB * VP)] = t2a + t2b;  // V[2][1]
+                dst[3 * (KCB * VP)] = t2b - t2a;  // V[2][2]
             }
             __builtin_amdgcn_sched_barrier(0);
+            UB::issue(ulane, p.Cin2, p.Nw, ch * KCB, lu_addr, wave);
+            __builtin_amdgcn_sched_barrier(0);
+            const bool pf = ch + 1 < nch;
+            if (pf) loadB(ch + 1);
+            __builtin_amdgcn_sched_barrier(0);
             if (pf)
-                wait_vmcnt<RB::NLOADS>();
+                wait_vmcnt<2 * NITB>();  // this wave's U rows have landed; the centre loads of chunk ch+1 stay in flight
             else
                 wait_vmcnt<0>();
-            lds_barrier();
-            gemm_steps<4 * (KC / 4), NT, VP>(afrag0, afrag1, bfrag, acc, [](int s) {
-                const int q = s / (KC / 4);
+            lds_barrier();  // V visible, every wave's U rows landed
+            gemm_steps<4 * (KCB / 4), NT, VP>(afrag0, afrag1, bfrag, acc, [](int s) {
+                const int q = s / (KCB / 4);
                 return (q >> 1) * 4 + (q & 1) + 5;  // 5, 6, 9, 10
             });
-        };
-        for (int ch = 0; ch < nch; ch += 2) {
-            chunk(ch, std::integral_constant<int, 0>{});
-            chunk(ch + 1, std::integral_constant<int, 1>{});
         }
     }
 
@@ -584,7 +543,7 @@ hipError_t lass_launch_wino(ConvKind kind, const ConvArgs& p, hipStream_t stream
             if (!p.res) return hipErrorInvalidValue;
             return launch_wino<F_RES>(p, stream);
         case CONV2_SHORTCUT:
-            if (!p.in2 || !p.w2_wino || !p.bias || p.Cin2 % (2 * KC) != 0) return hipErrorInvalidValue;
+            if (!p.in2 || !p.w2_wino || !p.bias || p.Cin2 % KCB != 0) return hipErrorInvalidValue;
             return launch_wino<F_PHASEB | F_BIAS>(p, stream);
         case CONV1_ACT_PRE:
             if (!p.pro_scale || !p.pro_shift || !p.epi_scale || !p.epi_shift || !p.pre_w || !p.pre_b || p.N != 32 ||

@@ -1,0 +1,57 @@
+// wino_common.h - pieces shared by the two Winograd F(2x2,3x3) kernels (wino.hip: 4-wave workgroups, phases separated by
+// barriers; wino_ws.hip: persistent 8-wave workgroups with producer / consumer waves).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "kernels.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__device__ __forceinline__ void lds_barrier() {  // workgroup barrier that does NOT drain vmcnt (LDS-DMA stays in flight)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {  // all but the N youngest vector-memory operations are complete
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// One 1-KiB LDS-DMA piece: 64 lanes x 16 B from `g` (per lane) to LDS byte address `lds_addr` (wave-uniform, + lane*16).
+// Issued from inline asm so that hipcc does not know about the pending LDS write: with the builtin it drains vmcnt(0)
+// in front of the next ds_read.  Completion is tracked by hand (wait_vmcnt).
+__device__ __forceinline__ void lds_dma_16B(const float* g, unsigned lds_addr) {
+    const unsigned a = __builtin_amdgcn_readfirstlane(lds_addr);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(g), "s"(a)
+                 : "memory");
+}
+
+// S k-steps of 2 MFMAs (v_mfma_f32_16x16x4_f32); LDS row of step s = s*4 (+ lane>>4).  The three fragment reads of
+// step s+PFD are issued before the MFMAs of step s (pinned: hipcc sinks them otherwise and then waits lgkmcnt(0) in
+// front of every MFMA pair).
+template <int S, int UPITCH, int VPITCH, typename XiOf>
+__device__ __forceinline__ void gemm_steps(const float* afrag0, const float* afrag1, const float* bfrag,
+                                           f32x4 (&acc)[16][2], XiOf xi_of) {
+    constexpr int PFD = 3;
+    float bv[PFD + 1], a0[PFD + 1], a1[PFD + 1];
+    auto rd = [&](int s) {
+        bv[s % (PFD + 1)] = bfrag[(s * 4) * VPITCH];
+        a0[s % (PFD + 1)] = afrag0[(s * 4) * UPITCH];
+        a1[s % (PFD + 1)] = afrag1[(s * 4) * UPITCH];
+    };
+#pragma unroll
+    for (int s = 0; s < PFD && s < S; ++s) rd(s);
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        if (s + PFD < S) rd(s + PFD);
+        __builtin_amdgcn_sched_barrier(0);
+        const int xi = xi_of(s);
+        acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s % (PFD + 1)], bv[s % (PFD + 1)], acc[xi][0], 0, 0, 0);
+        acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s % (PFD + 1)], bv[s % (PFD + 1)], acc[xi][1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+}  // namespace
