@@ -84,7 +84,7 @@ struct lass_ctx {
     std::vector<void*> owned;        // derived device buffers to free
     // profiling
     int compute_mode = LASS_COMPUTE_F32;
-    int wino = 1;              // Winograd F(2x2,3x3) for the 3x3 convs at W >= 32: 1 = wino.hip, 2 = wino_ws.hip (LASS_WINO=0: direct only)
+    bool wino = true;          // Winograd F(2x2,3x3) kernels for the 3x3 convs at W >= 32 (LASS_WINO=0: direct only)
     bool fuse_preconv = true;  // LASS_FUSE_PRECONV=0 materialises pre_conv's output with its own kernel
     bool fuse_pool = true;  // LASS_FUSE_POOL=0 selects the stand-alone pool kernel (A/B + parity of both paths)
     bool profiling = false;
@@ -291,13 +291,6 @@ void prof_collect(lass_ctx* c) {
 // x: (B,cin,H,W) batch stride x_bs; out: batch stride out_bs (may be a channel slice of a concat buffer).
 // pool_out (optional): the block's avg-pooled output (B,cout,H/pool_h,W/2), produced by conv2's epilogue.
 // x0 (optional, encoder_block1 only): the block input is pre_conv(x0) and is formed on the fly - x is then ignored.
-// wino_ws.hip needs Cin2 % 32 == 0 for the shortcut phase; anything it does not take goes to wino.hip
-hipError_t launch_wino_any(lass_ctx* c, ConvKind kind, const ConvArgs& p, hipStream_t st) {
-    if (c->wino == 2 && lass_wino_ws_supported(p) && (kind != CONV2_SHORTCUT || p.Cin2 % 32 == 0))
-        return lass_launch_wino_ws(kind, p, st);
-    return lass_launch_wino(kind, p, st);
-}
-
 int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int B, int H, int W, const float* shift,
                  float* a2, float* out, long out_bs, hipStream_t st, float* pool_out = nullptr, int pool_h = 2,
                  const float* x0 = nullptr) {
@@ -322,7 +315,7 @@ int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int
         if (bf1)
             HIP_TRY(c, lass_launch_conv_bf16(CONV1_ACT, p, st));
         else if (wino1)
-            HIP_TRY(c, launch_wino_any(c, x0 ? CONV1_ACT_PRE : CONV1_ACT, p, st));
+            HIP_TRY(c, lass_launch_wino(x0 ? CONV1_ACT_PRE : CONV1_ACT, p, st));
         else
             HIP_TRY(c, lass_launch_conv(x0 ? CONV1_ACT_PRE : CONV1_ACT, p, st));
     }
@@ -345,7 +338,7 @@ int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int
         if (bf2)
             HIP_TRY(c, lass_launch_conv_bf16(CONV2_IDENT, q, st));
         else if (wino2)
-            HIP_TRY(c, launch_wino_any(c, x0 ? CONV2_IDENT_PRE : CONV2_IDENT, q, st));
+            HIP_TRY(c, lass_launch_wino(x0 ? CONV2_IDENT_PRE : CONV2_IDENT, q, st));
         else
             HIP_TRY(c, lass_launch_conv(x0 ? CONV2_IDENT_PRE : CONV2_IDENT, q, st));
     } else {
@@ -353,7 +346,7 @@ int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int
         if (bf2)
             HIP_TRY(c, lass_launch_conv_bf16(CONV2_SHORTCUT, q, st));
         else if (wino2)
-            HIP_TRY(c, launch_wino_any(c, CONV2_SHORTCUT, q, st));
+            HIP_TRY(c, lass_launch_wino(CONV2_SHORTCUT, q, st));
         else
             HIP_TRY(c, lass_launch_conv(CONV2_SHORTCUT, q, st));
     }
@@ -473,7 +466,7 @@ int lass_create(lass_ctx** out, int device_id) {
     }
     lass_ctx* c = new lass_ctx();
     c->device = device_id;
-    if (const char* e = getenv("LASS_WINO")) c->wino = atoi(e);
+    if (const char* e = getenv("LASS_WINO")) c->wino = atoi(e) != 0;
     if (const char* e = getenv("LASS_FUSE_POOL")) c->fuse_pool = atoi(e) != 0;
     if (const char* e = getenv("LASS_FUSE_PRECONV")) c->fuse_preconv = atoi(e) != 0;
     c->prof.resize(P_COUNT);

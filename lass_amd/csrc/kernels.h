@@ -48,7 +48,6 @@ struct ConvArgs {
     float* pool_out = nullptr;  // fused avg-pool of the output: (B, N, H/pool_h, W/2) dense
     int pool_h = 2;              // vertical pool factor (1 or 2); horizontal is 2
     long long* dbg = nullptr;  // diagnostic builds (-DLASS_CONV_DIAG) only: 8 int64 per block
-    int dbg_mode = 0;          // diagnostic builds only: timing experiments that skip parts of the work (results invalid)
 };
 
 enum ConvKind { CONV1_ACT = 0, CONV2_IDENT = 1, CONV2_SHORTCUT = 2, TCONV_ACT = 3, CONV1_ACT_PRE = 4, CONV2_IDENT_PRE = 5 };
@@ -60,10 +59,6 @@ bool lass_wino_supported(const ConvArgs& p);
 hipError_t lass_launch_wino(ConvKind kind, const ConvArgs& p, hipStream_t stream);
 hipError_t lass_launch_wino_weights(const float* w, int Cout, int Cin, float* U, hipStream_t stream);
 hipError_t lass_launch_wino_shortcut_weights(const float* w, int Cout, int Cin, float* U, hipStream_t stream);
-
-// ---- wino_ws.hip (persistent producer/consumer-wave schedule of the same Winograd arithmetic; same weights) ----------
-bool lass_wino_ws_supported(const ConvArgs& p);
-hipError_t lass_launch_wino_ws(ConvKind kind, const ConvArgs& p, hipStream_t stream);
 
 // ---- conv_bf16.hip (bf16-MFMA variant of the 3x3 kinds; W multiple of 32, Cin multiple of 16) ----------------------
 bool lass_bf16_supported(const ConvArgs& p);

@@ -1,5 +1,4 @@
-// wino_common.h - pieces shared by the two Winograd F(2x2,3x3) kernels (wino.hip: 4-wave workgroups, phases separated by
-// barriers; wino_ws.hip: persistent 8-wave workgroups with producer / consumer waves).
+// wino_common.h - LDS-DMA / barrier / MFMA-step helpers of the Winograd F(2x2,3x3) kernel (wino.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 #include "kernels.h"
