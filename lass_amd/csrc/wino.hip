@@ -43,7 +43,7 @@ struct RawStage {
     static constexpr int NGRP = KCH / G;
     static constexpr int GRP_ELEMS = G * CH_ELEMS;
     static constexpr int NPASS = (GRP_ELEMS + NTHREADS - 1) / NTHREADS;
-    int goff[NPASS];
+    unsigned goff[NPASS];  // BYTE offset of this thread's element from the chunk's first channel (uniform base + 32-bit lane offset -> saddr loads)
     unsigned okbits;
     float v[PRE ? 1 : 2][PRE ? 1 : NGRP][NPASS];  // two chunks in flight (PRE: x0 at this thread's positions, loaded once)
 
@@ -61,22 +61,29 @@ struct RawStage {
             const int r = w / IP, x = w % IP;
             const int gy = y0 + r - HALO, gx = x0 + x - HALO;
             const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
-            goff[k] = cl * H * W + min(max(gy, 0), H - 1) * W + min(max(gx, 0), W - 1);
+            goff[k] = 4u * (unsigned)(cl * H * W + min(max(gy, 0), H - 1) * W + min(max(gx, 0), W - 1));
             okbits |= (ok ? 1u : 0u) << k;
         }
     }
     static constexpr int NLOADS = NGRP * NPASS;  // vector-memory loads load() issues (counted by the vmcnt waits)
+    // rsrc: buffer descriptor of this batch item's input planes; c0_bytes: byte offset of the chunk's first channel.
+    // buffer_load with a scalar offset + constant 32-bit lane offset: no VALU address arithmetic per load.
     template <int BUF>
-    __device__ __forceinline__ void load(const float* __restrict__ in_c0, int HW) {
+    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rsrc, unsigned c0_bytes, int HW) {
         if (PRE) return;  // nothing per chunk: every channel is an affine function of the one x0 plane
 #pragma unroll
         for (int q = 0; q < NGRP; ++q)
 #pragma unroll
-            for (int k = 0; k < NPASS; ++k) v[BUF][q][k] = in_c0[(size_t)q * G * HW + goff[k]];
+            for (int k = 0; k < NPASS; ++k)
+                v[BUF][q][k] = __builtin_bit_cast(
+                    float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)goff[k], (int)(c0_bytes + (unsigned)(q * G * HW) * 4u), 0));
     }
     __device__ __forceinline__ void load_x0(const float* __restrict__ x0_b, int HW) {  // PRE only
 #pragma unroll
-        for (int k = 0; k < NPASS; ++k) v[0][0][k] = x0_b[goff[k] >= HW ? goff[k] - HW : goff[k]];
+        for (int k = 0; k < NPASS; ++k) {
+            const unsigned e = goff[k] / 4u;
+            v[0][0][k] = x0_b[e >= (unsigned)HW ? e - HW : e];
+        }
     }
     // lsc / lsh: the prologue scale / shift of this chunk's channels in LDS (staged once per workgroup); all table reads
     // are issued up front (uniform b128 reads) so the element loop below has no LDS read behind an LDS write.
@@ -133,20 +140,21 @@ struct UDma {
     static constexpr int NINSTR = NXI * KCH / RPI / 4;   // wave-instructions per wave
     static_assert(NXI * KCH % (RPI * 4) == 0 && KCH % RPI == 0, "rows split evenly; an instruction stays in one xi slot");
     // Per-lane part of the source address (constant over chunks and instructions): row-in-instruction * Nw + swizzled col
-    __device__ __forceinline__ static const float* lane_base(const float* Uw, int Nw, int n0, int lane) {
+    // returned as a 32-bit BYTE offset from Uw + n0, so that an instruction's address is (uniform pointer) + (lane offset)
+    __device__ __forceinline__ static unsigned lane_base(int Nw, int lane) {
         const int rl = lane / (NT / 4);                  // row within the instruction's RPI rows
         const int colpos = (lane % (NT / 4)) * 4;
-        return Uw + (size_t)rl * Nw + n0 + (colpos ^ ((rl & 1) << 4));  // r0 is even, so (r & 1) == (rl & 1)
+        return 4u * (unsigned)(rl * Nw + (colpos ^ ((rl & 1) << 4)));  // r0 is even, so (r & 1) == (rl & 1)
     }
     // lds_base: LDS byte address of lu (uniform).  c0: first channel of the chunk.
-    __device__ __forceinline__ static void issue(const float* lane_ptr, int Cin, int Nw, int c0, unsigned lds_base,
-                                                 int wave) {
+    __device__ __forceinline__ static void issue(v4i32 rsrc, unsigned lane_off, int Cin, int Nw, int c0,
+                                                 unsigned lds_base, int wave) {
 #pragma unroll
         for (int i = 0; i < NINSTR; ++i) {
             const int r0 = (wave * NINSTR + i) * RPI;    // wave-uniform
             const int xi = r0 / KCH, c = r0 % KCH;
-            const float* g = lane_ptr + ((size_t)xi * Cin + c0 + c) * Nw;
-            lds_dma_16B(g, lds_base + (unsigned)(r0 * NT * 4));  // M0 = wave-uniform LDS byte address of this 1-KiB piece
+            const unsigned soff = (unsigned)((xi * Cin + c0 + c) * Nw) * 4u;  // uniform
+            lds_dma_16B(rsrc, lane_off, soff, lds_base + (unsigned)(r0 * NT * 4));  // M0 = LDS byte address of this 1-KiB piece
         }
     }
 };
@@ -190,7 +198,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
     float* lds_pb = lds_pw + 32;
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // uniform to the compiler too
     const int wco = wave / WWT, wwt = wave % WWT;
     const int b = blockIdx.z;
     const int n0 = blockIdx.y * NT;
@@ -245,9 +253,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
         ra.init(tid, y0, x0, p.H, p.W);
         const int nch = p.Cin / KC;  // even (host-checked)
         if (PRE) ra.load_x0(in_b, HW);
-        ra.template load<0>(in_b, HW);
-        ra.template load<1>(in_b + (size_t)KC * HW, HW);
-        const float* ulane = UA::lane_base(p.w_wino, p.Nw, n0, lane);
+        const __amdgpu_buffer_rsrc_t in_rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_b), 0, (PRE ? 1 : p.Cin) * HW * 4, 0x00020000);
+        ra.template load<0>(in_rsrc, 0u, HW);
+        ra.template load<1>(in_rsrc, (unsigned)(KC * HW) * 4u, HW);
+        const unsigned ulane = UA::lane_base(p.Nw, lane);
+        const v4i32 uw_n0 = make_rsrc_words(p.w_wino + n0, (unsigned)(16 * p.Cin * p.Nw - n0) * 4u);
         lds_barrier();  // prologue tables visible
         auto chunk = [&](int ch, auto buf) {
             constexpr int BUF = decltype(buf)::value;
@@ -260,10 +271,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
 #endif
             ra.template store<BUF>(lraw, lds_sc + ch * KC, lds_sh + ch * KC, tid, lds_pw + ch * KC, lds_pb + ch * KC);
             __builtin_amdgcn_sched_barrier(0);
-            UA::issue(ulane, p.Cin, p.Nw, ch * KC, lu_addr, wave);
+            UA::issue(uw_n0, ulane, p.Cin, p.Nw, ch * KC, lu_addr, wave);
             __builtin_amdgcn_sched_barrier(0);
             const bool pf = ch + 2 < nch;
-            if (pf) ra.template load<BUF>(in_b + (size_t)(ch + 2) * KC * HW, HW);
+            if (pf) ra.template load<BUF>(in_rsrc, (unsigned)((ch + 2) * KC * HW) * 4u, HW);
             __builtin_amdgcn_sched_barrier(0);
 #ifdef LASS_CONV_DIAG
             const long long t2 = clock64();
@@ -338,19 +349,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
         const int wty = wt / PWT, wtx = wt % PWT;
         const int oy = y0 + 2 * wty, ox = x0 + 2 * wtx;
         const bool okB = oy + 1 < p.H;
-        const float* in2_t = p.in2 + (size_t)b * p.in2_bs + (size_t)cb * HW + (size_t)min(oy, p.H - 2) * p.W + ox;
+        const __amdgpu_buffer_rsrc_t in2_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(p.in2 + (size_t)b * p.in2_bs), 0, p.Cin2 * HW * 4, 0x00020000);
+        const unsigned voff1 = (unsigned)(cb * HW + min(oy, p.H - 2) * p.W + ox) * 4u, voff2 = voff1 + (unsigned)p.W * 4u;
         float2 rb[2 * NITB];
         auto loadB = [&](int ch) {
-            const float* pc = in2_t + (size_t)ch * KCB * HW;
 #pragma unroll
             for (int it = 0; it < NITB; ++it) {
-                rb[2 * it] = *reinterpret_cast<const float2*>(pc + (size_t)it * CSTEP * HW);
-                rb[2 * it + 1] = *reinterpret_cast<const float2*>(pc + (size_t)it * CSTEP * HW + p.W);
+                const unsigned soff = (unsigned)((ch * KCB + it * CSTEP) * HW) * 4u;
+                rb[2 * it] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(in2_rsrc, (int)voff1, (int)soff, 0));
+                rb[2 * it + 1] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(in2_rsrc, (int)voff2, (int)soff, 0));
             }
         };
         const int nch = p.Cin2 / KCB;
         loadB(0);
-        const float* ulane = UB::lane_base(p.w2_wino, p.Nw, n0, lane);
+        const unsigned ulane = UB::lane_base(p.Nw, lane);
+        const v4i32 uw_n0 = make_rsrc_words(p.w2_wino + n0, (unsigned)(4 * p.Cin2 * p.Nw - n0) * 4u);
         for (int ch = 0; ch < nch; ++ch) {
             lds_barrier();  // previous chunk's MFMAs have finished reading V / U
 #pragma unroll
@@ -366,7 +380,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
                 dst[3 * (KCB * VP)] = t2b - t2a;  // V[2][2]
             }
             __builtin_amdgcn_sched_barrier(0);
-            UB::issue(ulane, p.Cin2, p.Nw, ch * KCB, lu_addr, wave);
+            UB::issue(uw_n0, ulane, p.Cin2, p.Nw, ch * KCB, lu_addr, wave);
             __builtin_amdgcn_sched_barrier(0);
             const bool pf = ch + 1 < nch;
             if (pf) loadB(ch + 1);

@@ -15,16 +15,31 @@ __device__ __forceinline__ void wait_vmcnt() {  // all but the N youngest vector
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// One 1-KiB LDS-DMA piece: 64 lanes x 16 B from `g` (per lane) to LDS byte address `lds_addr` (wave-uniform, + lane*16).
-// Issued from inline asm so that hipcc does not know about the pending LDS write: with the builtin it drains vmcnt(0)
-// in front of the next ds_read.  Completion is tracked by hand (wait_vmcnt).
-__device__ __forceinline__ void lds_dma_16B(const float* g, unsigned lds_addr) {
-    const unsigned a = __builtin_amdgcn_readfirstlane(lds_addr);
+typedef int v4i32 __attribute__((ext_vector_type(4)));
+
+// Buffer descriptor words for inline-asm buffer ops (raw buffer, stride 0, `bytes` records), from wave-uniform inputs.
+__device__ __forceinline__ v4i32 make_rsrc_words(const void* base, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    v4i32 r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(a & 0xffffffffu));
+    r.y = __builtin_amdgcn_readfirstlane((int)(a >> 32));
+    r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+    r.w = 0x00020000;
+    return r;
+}
+
+// One 1-KiB LDS-DMA piece: 64 lanes x 16 B from (buffer base + scalar byte offset soff + per-lane byte offset) to LDS
+// byte address `lds_addr` (wave-uniform, + lane*16).  Scalar offset + constant 32-bit lane offset: no VALU address
+// arithmetic per piece (the f32 MFMA shares the SIMD's VALU issue).  Issued from inline asm so that hipcc does not know
+// about the pending LDS write: with the builtin it drains vmcnt(0) in front of the next ds_read.  Completion is tracked by
+// hand (wait_vmcnt).
+__device__ __forceinline__ void lds_dma_16B(v4i32 rsrc, unsigned lane_off, unsigned soff, unsigned lds_addr) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(g), "s"(a)
-                 : "memory");
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(lane_off), "s"(rsrc), "s"(soff), "s"(lds_addr)
+        : "memory");
 }
 
 // S k-steps of 2 MFMAs (v_mfma_f32_16x16x4_f32); LDS row of step s = s*4 (+ lane>>4).  The three fragment reads of
