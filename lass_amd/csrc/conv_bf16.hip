@@ -40,7 +40,8 @@ struct Phase16 {
     static constexpr int NWLD = (W1_U4 + NTHREADS - 1) / NTHREADS;
     static constexpr int LDS_U4 = IN_U4 + W_U4;
 
-    int goff[NPP];
+    unsigned goff[NPP];  // BYTE offset of this thread's pixel inside a channel plane (32-bit lane part of a buffer address)
+    unsigned woff[NWLD]; // BYTE offset of this thread's 16-B weight units inside a chunk's slab
     unsigned okbits;
     float v[2][NPP][8];  // prefetched f32 activations: [octet][pass][channel in octet]
     uint4 wv[SPLIT][NWLD];  // prefetched bf16 weights (hi, lo)
@@ -58,27 +59,38 @@ struct Phase16 {
             const int r = u / IP, x = u % IP;
             const int gy = y0 + r - HALO, gx = x0 + x - HALO;
             const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
-            goff[k] = min(max(gy, 0), H - 1) * W + min(max(gx, 0), W - 1);
+            goff[k] = 4u * (unsigned)(min(max(gy, 0), H - 1) * W + min(max(gx, 0), W - 1));
             okbits |= (ok ? 1u : 0u) << k;
         }
     }
-    // in_c0: channel c0 of this clip (f32 planes); wb: this chunk's weight slab [tap][octet][Cout] in 16-B units, + n0
-    __device__ __forceinline__ void load(const float* __restrict__ in_c0, int HW, const uint4* __restrict__ wb,
-                                         const uint4* __restrict__ wb_lo, int Cout, const float* __restrict__ sc,
-                                         const float* __restrict__ sh, int tid) {
-#pragma unroll
-        for (int o = 0; o < 2; ++o)
-#pragma unroll
-            for (int k = 0; k < NPP; ++k)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[o][k][j] = in_c0[(size_t)(o * 8 + j) * HW + goff[k]];
+    __device__ __forceinline__ void init_w(int tid, int Cout) {
 #pragma unroll
         for (int i = 0; i < NWLD; ++i) {
             const int e0 = tid + i * NTHREADS;
             const int e = e0 < W1_U4 ? e0 : W1_U4 - 1;
             const int row = e / NT, col = e % NT;  // row = tap*2 + octet
-            wv[0][i] = wb[(size_t)row * Cout + col];
-            if (SPLIT == 2) wv[1][i] = wb_lo[(size_t)row * Cout + col];
+            woff[i] = 16u * (unsigned)(row * Cout + col);
+        }
+    }
+    // Buffer-addressed loads (descriptor + scalar byte offset + constant 32-bit lane offset: no VALU address arithmetic).
+    // in_rs: this clip's input planes, c0b = byte offset of the chunk's first channel; w_rs / wl_rs: the weight matrix
+    // (hi / lo) from column n0 on, wb = byte offset of the chunk's slab [tap][octet][Cout].
+    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t in_rs, unsigned c0b, int HW, __amdgpu_buffer_rsrc_t w_rs,
+                                         __amdgpu_buffer_rsrc_t wl_rs, unsigned wb, const float* __restrict__ sc,
+                                         const float* __restrict__ sh) {
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int k = 0; k < NPP; ++k)
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    v[o][k][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                               in_rs, (int)goff[k], (int)(c0b + (unsigned)((o * 8 + j) * HW) * 4u), 0));
+#pragma unroll
+        for (int i = 0; i < NWLD; ++i) {
+            wv[0][i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(w_rs, (int)woff[i], (int)wb, 0));
+            if (SPLIT == 2)
+                wv[1][i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wl_rs, (int)woff[i], (int)wb, 0));
         }
         if (PRO) {
 #pragma unroll
@@ -224,16 +236,25 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
 
     PA pa;
     PB pb;
+    const auto rs = [](const void* ptr, long bytes) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, (int)bytes, 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t in_rs = rs(in_b, (long)p.Cin * HW * 4);
+    const __amdgpu_buffer_rsrc_t wa_rs = rs(wa, ((long)(p.Cin / KB) * TAPS * 2 * p.Nw - n0) * 16);
+    const __amdgpu_buffer_rsrc_t wal_rs = SPLIT == 2 ? rs(wa_lo, ((long)(p.Cin / KB) * TAPS * 2 * p.Nw - n0) * 16) : wa_rs;
+    const __amdgpu_buffer_rsrc_t in2_rs = HASB ? rs(in2_b, (long)p.Cin2 * HW * 4) : in_rs;
+    const __amdgpu_buffer_rsrc_t wb_rs = HASB ? rs(wb2, ((long)(p.Cin2 / KB) * 2 * p.Nw - n0) * 16) : wa_rs;
+    const __amdgpu_buffer_rsrc_t wbl_rs = (HASB && SPLIT == 2) ? rs(wb2_lo, ((long)(p.Cin2 / KB) * 2 * p.Nw - n0) * 16) : wb_rs;
     auto loadA = [&](int c) {
-        pa.load(in_b + (size_t)c * KB * HW, HW, wa + (size_t)c * TAPS * 2 * p.Nw, wa_lo + (size_t)c * TAPS * 2 * p.Nw, p.Nw,
-                sc + c * KB, sh + c * KB, tid);
+        pa.load(in_rs, (unsigned)(c * KB * HW) * 4u, HW, wa_rs, wal_rs, (unsigned)(c * TAPS * 2 * p.Nw) * 16u, sc + c * KB,
+                sh + c * KB);
     };
     auto loadB = [&](int c) {
-        pb.load(in2_b + (size_t)c * KB * HW, HW, wb2 + (size_t)c * 2 * p.Nw, wb2_lo + (size_t)c * 2 * p.Nw, p.Nw, nullptr,
-                nullptr, tid);
+        pb.load(in2_rs, (unsigned)(c * KB * HW) * 4u, HW, wb_rs, wbl_rs, (unsigned)(c * 2 * p.Nw) * 16u, nullptr, nullptr);
     };
 
     pa.init(tid, y0, x0, p.H, p.W);
+    pa.init_w(tid, p.Nw);
     loadA(0);
     __syncthreads();
     pa.store(lds4, tid);
@@ -258,6 +279,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
     float rtmp[RES_PF ? NPX : 1][16];
     if (HASB) {
         pb.init(tid, y0, x0, p.H, p.W);
+        pb.init_w(tid, p.Nw);
         loadB(0);
     }
     if (RES_PF) {
