@@ -90,6 +90,15 @@ int lass_separate(lass_ctx* ctx, const float* mixture, const float* condition, f
 int lass_stft_magphase(lass_ctx* ctx, const float* wav, int B, int L, float* mag, float* cos_out, float* sin_out,
                        float* real_out, float* imag_out, void* stream);
 
+/* Multi-resolution analysis front end ("next" row f3): n_windows centred STFTs of the same waveforms in one launch
+ * (n_fft = win_length in {256,512,1024,2048}, periodic Hann, reflect pad, common hop), each as magnitude / cos / sin
+ * with torchlibrosa-magphase semantics (mag = sqrt(re^2+im^2); cos = re/max(mag,1e-10); sin likewise).
+ * wav (B,L) -> mag[i], cos_out[i], sin_out[i] (B,T,win_lengths[i]/2+1), T = 1 + L/hop; at most 4 windows.
+ * Replaces: calculate_stft_components (scripts/precompute_stfts.py:19-58) looped over stft_win_lengths (:573-590;
+ * config stft_win_lengths [256,512,2048], hop 160). */
+int lass_multi_stft(lass_ctx* ctx, const float* wav, int B, int L, int hop, int n_windows, const int* win_lengths,
+                    float* const* mag, float* const* cos_out, float* const* sin_out, void* stream);
+
 /* Inverse STFT: real, imag (B,T,513) -> wav (B,L).  frames_ws: scratch of B*T*1024 floats.
  * Replaces: torchlibrosa ISTFT.forward as called at resunet.py:510. */
 int lass_istft(lass_ctx* ctx, const float* real, const float* imag, int B, int T, int L, float* wav,

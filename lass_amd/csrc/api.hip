@@ -72,6 +72,7 @@ struct lass_ctx {
     bool finalized = false;
     float2* tw = nullptr;
     float* win = nullptr;
+    float2* tw2k = nullptr;  // 2048-point twiddles for the multi-resolution analysis (lass_multi_stft)
     std::vector<Site> sites;
     std::map<std::string, int> site_idx;
     int n_shift = 0;
@@ -485,7 +486,14 @@ int lass_create(lass_ctx** out, int device_id) {
         tw[k] = make_float2((float)std::cos(a), (float)std::sin(a));
         win[k] = (float)(0.5 - 0.5 * std::cos(a));
     }
-    if (hipMalloc((void**)&c->tw, sizeof(float2) * LASS_NFFT) != hipSuccess ||
+    std::vector<float2> tw2k(2048);
+    for (int k = 0; k < 2048; ++k) {
+        const double a = 2.0 * M_PI * k / 2048.0;
+        tw2k[k] = make_float2((float)std::cos(a), (float)std::sin(a));
+    }
+    if (hipMalloc((void**)&c->tw2k, sizeof(float2) * 2048) != hipSuccess ||
+        hipMemcpy(c->tw2k, tw2k.data(), sizeof(float2) * 2048, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMalloc((void**)&c->tw, sizeof(float2) * LASS_NFFT) != hipSuccess ||
         hipMalloc((void**)&c->win, sizeof(float) * LASS_NFFT) != hipSuccess ||
         hipMemcpy(c->tw, tw.data(), sizeof(float2) * LASS_NFFT, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(c->win, win.data(), sizeof(float) * LASS_NFFT, hipMemcpyHostToDevice) != hipSuccess) {
@@ -505,6 +513,7 @@ int lass_destroy(lass_ctx* c) {
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     (void)hipFree(c->tw);
     (void)hipFree(c->win);
+    (void)hipFree(c->tw2k);
     delete c;
     return 0;
 }
@@ -701,6 +710,23 @@ int lass_stft_magphase(lass_ctx* c, const float* wav, int B, int L, float* mag, 
     const int T = 1 + L / LASS_HOP;
     HIP_TRY(c, lass_launch_stft(wav, B, L, T, T, c->tw, c->win, mag, cos_out, sin_out, real_out, imag_out, nullptr,
                                 nullptr, nullptr, (hipStream_t)stream));
+    return 0;
+}
+
+int lass_multi_stft(lass_ctx* c, const float* wav, int B, int L, int hop, int n_windows, const int* win_lengths,
+                    float* const* mag, float* const* cos_out, float* const* sin_out, void* stream) {
+    if (!c || !wav || !win_lengths || !mag || !cos_out || !sin_out || B <= 0 || hop <= 0 || n_windows <= 0 ||
+        n_windows > LASS_MAX_STFT_WINDOWS)
+        return fail(c, LASS_ERR_ARG, "lass_multi_stft: bad argument");
+    for (int i = 0; i < n_windows; ++i) {
+        const int N = win_lengths[i];
+        if (N != 256 && N != 512 && N != 1024 && N != 2048)
+            return fail(c, LASS_ERR_ARG, "lass_multi_stft: window lengths must be 256, 512, 1024 or 2048");
+        if (L <= N / 2) return fail(c, LASS_ERR_ARG, "lass_multi_stft: waveform shorter than the reflect padding");
+        if (!mag[i] || !cos_out[i] || !sin_out[i]) return fail(c, LASS_ERR_ARG, "lass_multi_stft: null output");
+    }
+    HIP_TRY(c, lass_launch_multi_stft(wav, B, L, hop, n_windows, win_lengths, c->tw2k, mag, cos_out, sin_out,
+                                      (hipStream_t)stream));
     return 0;
 }
 

@@ -55,7 +55,8 @@ struct Phase {
     // Every global load below is UNCONDITIONAL (addresses clamped into the image / the weight slab, the padding zero
     // applied by a select when the element is written to LDS): a conditional load makes hipcc branch around it and
     // drain vmcnt at the join, which serialises the prefetch behind a full memory round trip per chunk.
-    int goff[NPASS];        // clamped global offset of this thread's element in pass k of group 0
+    unsigned goff[NPASS];   // clamped BYTE offset of this thread's element in pass k of group 0 (lane part of a buffer address)
+    unsigned woff[NWLD];    // BYTE offset of this thread's weight float4s inside a chunk's slab
     unsigned okbits;        // bit k: the element of pass k lies inside the image (else conv zero padding)
     float v[NGRP][NPASS];   // prefetched input elements
     float4 wv[NWLD];        // prefetched weights
@@ -79,7 +80,7 @@ struct Phase {
             const int gy = y0 + r - HALO, gx = x0 + x - HALO;
             const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
             const int gyc = min(max(gy, 0), H - 1), gxc = min(max(gx, 0), W - 1);
-            goff[k] = cl * H * W + gyc * W + gxc;
+            goff[k] = 4u * (unsigned)(cl * H * W + gyc * W + gxc);
             okbits |= (ok ? 1u : 0u) << k;
         }
     }
@@ -88,7 +89,10 @@ struct Phase {
     // PRE: fetch x0 once per tile (goff's channel-local part must be dropped: there is one plane only)
     __device__ __forceinline__ void load_x0(const float* __restrict__ x0_b, int HW) {
 #pragma unroll
-        for (int k = 0; k < NPASS; ++k) x0v[k] = x0_b[goff[k] >= HW ? goff[k] - HW : goff[k]];
+        for (int k = 0; k < NPASS; ++k) {
+            const unsigned e = goff[k] / 4u;
+            x0v[k] = x0_b[e >= (unsigned)HW ? e - HW : e];
+        }
     }
     __device__ __forceinline__ void load_pre(const float* __restrict__ pw, const float* __restrict__ pb) {
 #pragma unroll
@@ -98,21 +102,31 @@ struct Phase {
         }
     }
 
-    __device__ __forceinline__ void load(const float* __restrict__ in_c0, int HW, const float* __restrict__ w_c0,
-                                         int Nw, const float* __restrict__ sc, const float* __restrict__ sh, int tid) {
-        if (!PRE) {
-#pragma unroll
-            for (int q = 0; q < NGRP; ++q)
-#pragma unroll
-                for (int k = 0; k < NPASS; ++k) v[q][k] = in_c0[(size_t)q * G * HW + goff[k]];
-        }
+    __device__ __forceinline__ void init_w(int tid, int Nw) {
 #pragma unroll
         for (int i = 0; i < NWLD; ++i) {
             const int e0 = tid + i * NTHREADS;  // float4 index into [KC*TAPS][NT/4]
             const int e = e0 < W_V4 ? e0 : W_V4 - 1;
             const int row = e / (NT / 4), col = e % (NT / 4);
-            wv[i] = *reinterpret_cast<const float4*>(w_c0 + (size_t)row * Nw + col * 4);
+            woff[i] = 4u * (unsigned)(row * Nw + col * 4);
         }
+    }
+    // Buffer-addressed (descriptor + scalar byte offset + constant lane offset: no VALU address arithmetic, which the f32
+    // MFMA would have to share the SIMD's VALU issue with).  in_rs: this clip's planes, c0b: byte offset of channel c0;
+    // w_rs: Wt from column n0 on, wb: byte offset of row c0*TAPS.
+    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t in_rs, unsigned c0b, int HW, __amdgpu_buffer_rsrc_t w_rs,
+                                         unsigned wb, const float* __restrict__ sc, const float* __restrict__ sh) {
+        if (!PRE) {
+#pragma unroll
+            for (int q = 0; q < NGRP; ++q)
+#pragma unroll
+                for (int k = 0; k < NPASS; ++k)
+                    v[q][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                            in_rs, (int)goff[k], (int)(c0b + (unsigned)(q * G * HW) * 4u), 0));
+        }
+#pragma unroll
+        for (int i = 0; i < NWLD; ++i)
+            wv[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(w_rs, (int)woff[i], (int)wb, 0));
         if (PRO) {
 #pragma unroll
             for (int c = 0; c < KC; ++c) {
@@ -193,10 +207,14 @@ struct Phase {
         float* buf0 = lds;
         float* buf1 = lds + buf_stride;
         init(tid, y0, x0, H, W);
+        init_w(tid, Nw);
         const int nchunks = Cin / KC;  // even (host-checked)
+        const __amdgpu_buffer_rsrc_t in_rs =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_b), 0, Cin * HW * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t w_rs =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Wt + n0), 0, (Cin * TAPS * Nw - n0) * 4, 0x00020000);
         auto ld = [&](int c) {
-            load(in_b + (size_t)c * KC * HW, HW, Wt + (size_t)c * KC * TAPS * Nw + n0, Nw, sc + c * KC, sh + c * KC,
-                 tid);
+            load(in_rs, (unsigned)(c * KC * HW) * 4u, HW, w_rs, (unsigned)(c * KC * TAPS * Nw) * 4u, sc + c * KC, sh + c * KC);
         };
         ld(0);
         __syncthreads();  // previous phase's LDS reads complete; epilogue tables visible
@@ -362,16 +380,24 @@ __global__ __launch_bounds__(NTHREADS) void conv_kernel_sb(ConvArgs p) {
 
     PA pa;
     PB pb;
+    const auto rs = [](const float* ptr, long bytes) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ptr), 0, (int)bytes, 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t in_rs = rs(in_b, (long)(PRE ? 1 : p.Cin) * HW * 4);
+    const __amdgpu_buffer_rsrc_t wa_rs = rs(p.w + n0, ((long)p.Cin * TAPS * p.Nw - n0) * 4);
+    const __amdgpu_buffer_rsrc_t in2_rs = HASB ? rs(in2_b, (long)p.Cin2 * HW * 4) : in_rs;
+    const __amdgpu_buffer_rsrc_t wb_rs = HASB ? rs(p.w2 + n0, ((long)p.Cin2 * p.Nw - n0) * 4) : wa_rs;
     auto loadA = [&](int c) {
-        pa.load(in_b + (size_t)c * KCA * HW, HW, p.w + (size_t)c * KCA * TAPS * p.Nw + n0, p.Nw, sc + c * KCA,
-                sh + c * KCA, tid);
+        pa.load(in_rs, (unsigned)(c * KCA * HW) * 4u, HW, wa_rs, (unsigned)(c * KCA * TAPS * p.Nw) * 4u, sc + c * KCA,
+                sh + c * KCA);
         if (PRE) pa.load_pre(p.pre_w + c * KCA, p.pre_b + c * KCA);
     };
     auto loadB = [&](int c) {
-        pb.load(in2_b + (size_t)c * 16 * HW, HW, p.w2 + (size_t)c * 16 * p.Nw + n0, p.Nw, nullptr, nullptr, tid);
+        pb.load(in2_rs, (unsigned)(c * 16 * HW) * 4u, HW, wb_rs, (unsigned)(c * 16 * p.Nw) * 4u, nullptr, nullptr);
     };
 
     pa.init(tid, y0, x0, p.H, p.W);
+    pa.init_w(tid, p.Nw);
     if (PRE) pa.load_x0(in_b, HW);
     loadA(0);
     __syncthreads();  // tables visible
@@ -417,6 +443,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_kernel_sb(ConvArgs p) {
     float rtmp[RES_PF ? NPX : 1][16];
     if (HASB) {
         pb.init(tid, y0, x0, p.H, p.W);
+        pb.init_w(tid, p.Nw);
         loadB(0);
     }
     if (RES_PF) {

@@ -9,6 +9,7 @@ constexpr int LASS_HOP = 160;
 constexpr int LASS_NBINS = 513;
 constexpr int LASS_FCROP = 512;
 constexpr int LASS_COND = 512;
+constexpr int LASS_MAX_STFT_WINDOWS = 4;
 
 // ---- conv.hip -----------------------------------------------------------------------------------------------------
 struct ConvArgs {
@@ -73,6 +74,12 @@ hipError_t lass_launch_weights_bf16(const float* w, int Cout, int Cin, int taps,
 hipError_t lass_launch_stft(const float* wav, int B, int L, int T, int Tpad, const float2* tw, const float* win,
                             float* mag, float* cosv, float* sinv, float* real, float* imag, float* x0,
                             const float* s0, const float* h0, hipStream_t stream);
+// Multi-resolution analysis (scripts/precompute_stfts.py:19-58,573-590): nwin centred STFTs (n_fft = win in {256, 512,
+// 1024, 2048}, periodic Hann, reflect pad, common hop) of the same waveforms in one launch, torchlibrosa-magphase
+// semantics (clamp on |X| at 1e-10).  Outputs (B, T, n_fft/2+1) each, T = 1 + L/hop.  tw2k: 2048 (cos, sin)(2*pi*k/2048).
+hipError_t lass_launch_multi_stft(const float* wav, int B, int L, int hop, int nwin, const int* n_fft,
+                                  const float2* tw2k, float* const* mag, float* const* cosv, float* const* sinv,
+                                  hipStream_t stream);
 hipError_t lass_launch_istft_frames(const float* real, const float* imag, int B, int T, const float2* tw,
                                     const float* win, float* frames, hipStream_t stream);
 hipError_t lass_launch_istft_ola(const float* frames, int B, int T, int L, const float* win, float* wav,

@@ -94,6 +94,102 @@ __global__ __launch_bounds__(256) void stft_kernel(const float* __restrict__ wav
     }
 }
 
+// N-point complex forward FFT for N in {256, 512, 1024, 2048}: radix-4 Stockham passes plus one radix-2 pass when log2 N
+// is odd; 256 threads, each taking (N/4)/256 butterflies per pass (or idling).  tw2k[m] = (cos, sin)(2*pi*m/2048).
+template <int N>
+__device__ __forceinline__ float2* fft_fwd(float2* a, float2* b, const float2* tw2k, int tid) {
+    constexpr int LOG2 = N == 256 ? 8 : N == 512 ? 9 : N == 1024 ? 10 : 11;
+    constexpr int NP4 = LOG2 / 2;
+    constexpr int TWS = 2048 / N;  // stride into the 2048-entry table
+    float2* src = a;
+    float2* dst = b;
+#pragma unroll
+    for (int pass = 0; pass < NP4; ++pass) {
+        const int p = 1 << (2 * pass);
+        for (int i = tid; i < N / 4; i += 256) {
+            const int k = i & (p - 1);
+            const int j = ((i - k) << 2) + k;
+            const int ts = (N / 4 / p) * TWS;
+            float2 u0 = src[i], u1 = src[i + N / 4], u2 = src[i + N / 2], u3 = src[i + 3 * N / 4];
+            if (pass > 0) {
+                u1 = ctw<false>(u1, tw2k[k * ts]);
+                u2 = ctw<false>(u2, tw2k[2 * k * ts]);
+                u3 = ctw<false>(u3, tw2k[3 * k * ts]);
+            }
+            const float2 a0 = cadd(u0, u2), a1 = csub(u0, u2), a2 = cadd(u1, u3);
+            float2 a3 = csub(u1, u3);
+            a3 = make_float2(a3.y, -a3.x);  // * (-i)
+            dst[j] = cadd(a0, a2);
+            dst[j + p] = cadd(a1, a3);
+            dst[j + 2 * p] = csub(a0, a2);
+            dst[j + 3 * p] = csub(a1, a3);
+        }
+        __syncthreads();
+        float2* t = src; src = dst; dst = t;
+    }
+    if (LOG2 & 1) {  // final radix-2 pass, p = N/2
+        for (int i = tid; i < N / 2; i += 256) {
+            const float2 u0 = src[i];
+            const float2 u1 = ctw<false>(src[i + N / 2], tw2k[i * TWS]);
+            dst[i] = cadd(u0, u1);
+            dst[i + N / 2] = csub(u0, u1);
+        }
+        __syncthreads();
+        float2* t = src; src = dst; dst = t;
+    }
+    return src;  // natural-order spectrum
+}
+
+struct MultiStftArgs {
+    int nwin;
+    int n_fft[LASS_MAX_STFT_WINDOWS];
+    float* mag[LASS_MAX_STFT_WINDOWS];
+    float* cosv[LASS_MAX_STFT_WINDOWS];
+    float* sinv[LASS_MAX_STFT_WINDOWS];
+};
+
+template <int N>
+__device__ __forceinline__ void stft_frame(const float* __restrict__ w, int L, int hop, int t, size_t row,
+                                           const float2* TW, float2* A, float2* Bf, float* __restrict__ mag,
+                                           float* __restrict__ cosv, float* __restrict__ sinv, int tid) {
+    constexpr int TWS = 2048 / N;
+    for (int idx = tid; idx < N; idx += 256) {
+        int n = t * hop + idx - N / 2;  // centre=True, reflect padding of n_fft/2
+        if (n < 0) n = -n;
+        if (n >= L) n = 2 * (L - 1) - n;
+        const float wn = 0.5f - 0.5f * TW[idx * TWS].x;  // periodic Hann
+        A[idx] = make_float2(w[n] * wn, 0.f);
+    }
+    __syncthreads();
+    const float2* X = fft_fwd<N>(A, Bf, TW, tid);
+    for (int f = tid; f <= N / 2; f += 256) {
+        const float re = X[f].x, im = X[f].y;
+        const float m = sqrtf(re * re + im * im);
+        const float den = fmaxf(m, 1e-10f);  // torchlibrosa magphase: the clamp is on |X| (precompute_stfts.py:51)
+        mag[row + f] = m;
+        cosv[row + f] = re / den;
+        sinv[row + f] = im / den;
+    }
+}
+
+// One launch for all analysis windows (they share the hop, hence T): blockIdx.z selects the window.
+__global__ __launch_bounds__(256) void multi_stft_kernel(const float* __restrict__ wav, int L, int T, int hop,
+                                                         const float2* __restrict__ tw2k, MultiStftArgs a) {
+    __shared__ float2 A[2048], Bf[2048], TW[2048];
+    const int t = blockIdx.x, b = blockIdx.y, z = blockIdx.z, tid = threadIdx.x;
+    for (int i = tid; i < 2048; i += 256) TW[i] = tw2k[i];
+    __syncthreads();
+    const int N = a.n_fft[z];
+    const float* w = wav + (size_t)b * L;
+    const size_t row = ((size_t)b * T + t) * (N / 2 + 1);
+    switch (N) {
+        case 256: stft_frame<256>(w, L, hop, t, row, TW, A, Bf, a.mag[z], a.cosv[z], a.sinv[z], tid); break;
+        case 512: stft_frame<512>(w, L, hop, t, row, TW, A, Bf, a.mag[z], a.cosv[z], a.sinv[z], tid); break;
+        case 1024: stft_frame<1024>(w, L, hop, t, row, TW, A, Bf, a.mag[z], a.cosv[z], a.sinv[z], tid); break;
+        default: stft_frame<2048>(w, L, hop, t, row, TW, A, Bf, a.mag[z], a.cosv[z], a.sinv[z], tid); break;
+    }
+}
+
 __global__ __launch_bounds__(256) void istft_frames_kernel(const float* __restrict__ real,
                                                            const float* __restrict__ imag, int T,
                                                            const float2* __restrict__ tw,
@@ -167,5 +263,22 @@ hipError_t lass_launch_istft_ola(const float* frames, int B, int T, int L, const
                                  hipStream_t stream) {
     if (B <= 0 || T <= 0 || L <= 0) return hipErrorInvalidValue;
     hipLaunchKernelGGL(istft_ola_kernel, dim3((L + 255) / 256, B), dim3(256), 0, stream, frames, T, L, win, wav);
+    return hipGetLastError();
+}
+
+hipError_t lass_launch_multi_stft(const float* wav, int B, int L, int hop, int nwin, const int* n_fft,
+                                  const float2* tw2k, float* const* mag, float* const* cosv, float* const* sinv,
+                                  hipStream_t stream) {
+    if (B <= 0 || hop <= 0 || nwin <= 0 || nwin > LASS_MAX_STFT_WINDOWS) return hipErrorInvalidValue;
+    MultiStftArgs a;
+    a.nwin = nwin;
+    for (int i = 0; i < nwin; ++i) {
+        const int N = n_fft[i];
+        if ((N != 256 && N != 512 && N != 1024 && N != 2048) || L <= N / 2 || !mag[i] || !cosv[i] || !sinv[i])
+            return hipErrorInvalidValue;
+        a.n_fft[i] = N; a.mag[i] = mag[i]; a.cosv[i] = cosv[i]; a.sinv[i] = sinv[i];
+    }
+    const int T = 1 + L / hop;
+    hipLaunchKernelGGL(multi_stft_kernel, dim3(T, B, nwin), dim3(256), 0, stream, wav, L, T, hop, tw2k, a);
     return hipGetLastError();
 }

@@ -127,6 +127,21 @@ class Engine:
         _lib.check(self.ctx, rc, "lass_stft_magphase")
         return (mag, cos, sin, re, im) if want_complex else (mag, cos, sin)
 
+    def multi_stft(self, wav: torch.Tensor, win_lengths, hop: int = arch.HOP):
+        """(B,L) -> {win: (mag, cos, sin)} each (B,1,T,win//2+1): every analysis window in ONE launch."""
+        wav = self._dev(wav)
+        B, L = wav.shape
+        T = 1 + L // hop
+        wins = [int(w) for w in win_lengths]
+        n = len(wins)
+        outs = {w: tuple(torch.empty(B, 1, T, w // 2 + 1, dtype=torch.float32, device=self.device) for _ in range(3))
+                for w in wins}
+        arr = lambda i: (c_void_p * n)(*[outs[w][i].data_ptr() for w in wins])  # noqa: E731
+        rc = self.lib.lass_multi_stft(self.ctx, _ptr(wav), B, L, hop, n, (c_int * n)(*wins), arr(0), arr(1), arr(2),
+                                      _stream(self.device))
+        _lib.check(self.ctx, rc, "lass_multi_stft")
+        return outs
+
     def istft(self, real: torch.Tensor, imag: torch.Tensor, length: int):
         real, imag = self._dev(real), self._dev(imag)
         B, T, F = real.shape

@@ -1,0 +1,155 @@
+"""Multi-resolution STFT front end and the precomputed-STFT wire format.
+
+Host-side mirror of the reference's pre-compute path:
+  * `calculate_stft_components`      scripts/precompute_stfts.py:19-58   (one window; same signature and outputs)
+  * `multi_resolution_stfts`         the loop at scripts/precompute_stfts.py:573-590, as ONE kernel launch
+  * `make_precomputed_items`         the per-item dict at scripts/precompute_stfts.py:596-622
+  * `save_batch_precomputed_data`    scripts/precompute_stfts.py:60-122  (`batch_%06d.pt`: a list of dicts)
+  * `PrecomputedSTFTDataset`         data/precomputed_stft_dataset.py:7-134 (file scan, cumulative index, one-file cache)
+
+All spectra are computed by liblass_hip (`lass_multi_stft`, lass_amd/csrc/stft.hip); there is no CPU fallback.
+The consumer of these files in the reference (`models/resunet_with_multistft.py`) is not runnable as shipped
+(SURVEY §2a), so only the producer side and the file format are reproduced.
+"""
+from __future__ import annotations
+
+import bisect
+import pathlib
+from typing import Any, Dict, List, Optional, Sequence
+
+import torch
+
+from ._lib import LassError
+from .engine import get_engine
+
+SUPPORTED_WINDOWS = (256, 512, 1024, 2048)
+
+
+def _check_cfg(n_fft, win_length, window, center, pad_mode):
+    if n_fft != win_length:
+        raise NotImplementedError("n_fft must equal win_length (scripts/precompute_stfts.py:577 sets n_fft = win_length)")
+    if win_length not in SUPPORTED_WINDOWS:
+        raise NotImplementedError(f"win_length must be one of {SUPPORTED_WINDOWS}")
+    if window != "hann" or not center or pad_mode != "reflect":
+        raise NotImplementedError("only window='hann', center=True, pad_mode='reflect' (config/*.yaml stft_* keys)")
+
+
+def _as_2d(waveform: torch.Tensor) -> torch.Tensor:
+    if waveform.dim() == 3:
+        waveform = waveform.squeeze(1)
+    if waveform.dim() != 2:
+        raise ValueError("waveform must be (batch, time) or (batch, 1, time)")
+    if waveform.device.type != "cuda":
+        raise LassError("lass_amd computes on an MI355X only: move the waveform to 'cuda' (no CPU fallback)")
+    return waveform.float().contiguous()
+
+
+def multi_resolution_stfts(waveform: torch.Tensor, win_lengths: Sequence[int], hop_length: int = 160,
+                           window: str = "hann", center: bool = True, pad_mode: str = "reflect"):
+    """{win_length: (magnitude, cos, sin)} each (B, 1, T, win_length//2+1), T = 1 + L // hop_length."""
+    for w in win_lengths:
+        _check_cfg(w, w, window, center, pad_mode)
+    x = _as_2d(waveform)
+    return get_engine(x.device).multi_stft(x, list(win_lengths), hop_length)
+
+
+def calculate_stft_components(waveform, n_fft, hop_length, win_length, window, center, pad_mode):
+    """scripts/precompute_stfts.py:19-58: (magnitude, cos_phase, sin_phase), each (B, 1, T, n_fft//2+1), contiguous."""
+    _check_cfg(n_fft, win_length, window, center, pad_mode)
+    return multi_resolution_stfts(waveform, [win_length], hop_length, window, center, pad_mode)[win_length]
+
+
+def make_precomputed_items(mixtures: torch.Tensor, segments: torch.Tensor, texts: Sequence[str],
+                           mixture_component_texts: Sequence[Sequence[str]], win_lengths: Sequence[int],
+                           hop_length: int = 160, window: str = "hann", center: bool = True,
+                           pad_mode: str = "reflect") -> List[Dict[str, Any]]:
+    """Per-item dicts exactly as scripts/precompute_stfts.py:596-622 builds them (tensors stay on the device; slices
+    `t[k:k+1]` keep the leading batch axis of size 1)."""
+    if mixtures.shape != segments.shape:
+        raise ValueError("mixtures and segments must have the same shape")
+    mix = multi_resolution_stfts(mixtures, win_lengths, hop_length, window, center, pad_mode)
+    seg = multi_resolution_stfts(segments, win_lengths, hop_length, window, center, pad_mode)
+    common = {"hop_length": hop_length, "window": window, "center": center, "pad_mode": pad_mode}
+    items = []
+    for k in range(mixtures.shape[0]):
+        items.append({
+            "stfts": {
+                "mixture": {w: tuple(t[k:k + 1] for t in mix[w]) for w in win_lengths},
+                "segment": {w: tuple(t[k:k + 1] for t in seg[w]) for w in win_lengths},
+            },
+            "target_waveform": segments[k],
+            "text": texts[k],
+            "mixture_component_texts": list(mixture_component_texts[k]),
+            "stft_common_params": dict(common),
+            "stft_win_lengths": list(win_lengths),
+        })
+    return items
+
+
+def _to_cpu(value):
+    if isinstance(value, torch.Tensor):
+        return value.detach().cpu()
+    if isinstance(value, tuple):
+        return tuple(_to_cpu(v) for v in value)
+    if isinstance(value, dict):
+        return {k: _to_cpu(v) for k, v in value.items()}
+    return value
+
+
+def save_batch_precomputed_data(output_dir, batch_index: int, batch_data_list: List[Dict[str, Any]]) -> int:
+    """scripts/precompute_stfts.py:60-122: one `batch_%06d.pt` per batch holding a list of CPU dicts; returns the number
+    of items written (0 for an empty list: no file is created)."""
+    if not batch_data_list:
+        print(f"Warning: Attempting to save empty data list for batch {batch_index}. Skipping file creation.")
+        return 0
+    output_dir = pathlib.Path(output_dir)
+    output_dir.mkdir(parents=True, exist_ok=True)
+    torch.save([_to_cpu(d) for d in batch_data_list], output_dir / f"batch_{batch_index:06d}.pt")
+    return len(batch_data_list)
+
+
+class PrecomputedSTFTDataset(torch.utils.data.Dataset):
+    """data/precomputed_stft_dataset.py:7-134: items of all `batch_*.pt` files in numeric order, addressed by a global
+    index through cumulative counts, with the most recently opened file cached.  Files are opened with
+    `torch.load(weights_only=True)`: they hold only tensors, strings, numbers, lists, tuples and dicts."""
+
+    def __init__(self, data_dir: str, expected_num_items: Optional[int] = None):
+        self.data_dir = pathlib.Path(data_dir)
+        if not self.data_dir.is_dir():
+            raise FileNotFoundError(f"Data directory not found: {self.data_dir}")
+        self.file_paths: List[pathlib.Path] = []
+        self.item_counts: List[int] = []
+        self.cumulative_counts: List[int] = [0]
+        for path in sorted(self.data_dir.glob("batch_*.pt"), key=lambda p: int(p.stem.split("_")[-1])):
+            try:
+                loaded = torch.load(path, map_location="cpu", weights_only=True)
+            except Exception as e:  # same policy as the reference: report and skip
+                print(f"Warning: Failed to load or process {path}. Skipping. Error: {e}")
+                continue
+            if not isinstance(loaded, list) or not loaded:
+                print(f"Warning: {path} does not hold a non-empty list. Skipping.")
+                continue
+            self.file_paths.append(path)
+            self.item_counts.append(len(loaded))
+            self.cumulative_counts.append(self.cumulative_counts[-1] + len(loaded))
+        self.total_items = self.cumulative_counts[-1]
+        if expected_num_items is not None and self.total_items != expected_num_items:
+            print(f"Warning: Found {self.total_items} items, but expected {expected_num_items}.")
+        self._cached_file_idx: Optional[int] = None
+        self._cached_data: Optional[List[Dict]] = None
+
+    def __len__(self) -> int:
+        return self.total_items
+
+    def __getitem__(self, idx: int) -> Dict[str, Any]:
+        if not 0 <= idx < self.total_items:
+            raise IndexError(f"Index {idx} out of bounds for dataset with size {self.total_items}")
+        file_idx = bisect.bisect_right(self.cumulative_counts, idx) - 1
+        if file_idx != self._cached_file_idx or self._cached_data is None:
+            try:
+                self._cached_data = torch.load(self.file_paths[file_idx], map_location="cpu", weights_only=True)
+                self._cached_file_idx = file_idx
+            except Exception as e:
+                self._cached_data, self._cached_file_idx = None, None
+                raise RuntimeError(f"Failed to load data file {self.file_paths[file_idx]}: {e}")
+        return self._cached_data[idx - self.cumulative_counts[file_idx]]

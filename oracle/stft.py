@@ -61,6 +61,12 @@ def magphase(real: torch.Tensor, imag: torch.Tensor):
     return mag, real / den, imag / den
 
 
+def stft_components(x: torch.Tensor, n_fft: int, hop: int = HOP):
+    """scripts/precompute_stfts.py:19-58 (`calculate_stft_components`): torchlibrosa STFT(n_fft = win_length, periodic
+    Hann, centre, reflect) followed by torchlibrosa `magphase` -> (mag, cos, sin), each (B, 1, T, n_fft//2+1)."""
+    return magphase(*stft_fft(x, n_fft, hop))
+
+
 def ola_envelope(frames: int, n_fft: int = N_FFT, hop: int = HOP, dtype=torch.float64) -> torch.Tensor:
     """sum_t w^2[n - hop*t], clamped at 1e-11 (librosa window_sumsquare as used by torchlibrosa ISTFT)."""
     n = n_fft + hop * (frames - 1)
