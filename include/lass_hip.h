@@ -135,6 +135,14 @@ int lass_mask_apply(lass_ctx* ctx, const float* x12, const float* mag, const flo
  * a = (eps32 + <ref,est>)/(<ref,ref> + eps32), eps32 = FLT_EPSILON.  dB math is the host's. */
 int lass_sdr_stats(lass_ctx* ctx, const float* ref, const float* est, int B, int L, double* stats, void* stream);
 
+/* Evaluator data path ("next" row f1): build B mixtures at given SNRs on the device.
+ * source (B,L) in/out, noise (B,L), snr_db (B) -> mixture (B,L):
+ *   mixture = source + noise * sqrt(mean(source^2) / 10^(snr/10) / mean(noise^2));
+ *   if max|mixture| > 1: source *= 0.9/max and mixture *= 0.9/max   (declipping; source is modified in place).
+ * scratch: 4*B doubles.  Replaces: the numpy mixing block of DCASEEvaluator.__call__ (dcase_evaluator.py:77-89). */
+int lass_mix_at_snr(lass_ctx* ctx, float* source, const float* noise, const float* snr_db, float* mixture, int B, int L,
+                    double* scratch, void* stream);
+
 /* ---- instrumentation ---------------------------------------------------------------------------------------- */
 
 /* When enabled, lass_separate brackets each kernel class with HIP events on `stream` (costs a few us per launch). */

@@ -780,6 +780,14 @@ int lass_sdr_stats(lass_ctx* c, const float* ref, const float* est, int B, int L
     return 0;
 }
 
+int lass_mix_at_snr(lass_ctx* c, float* source, const float* noise, const float* snr_db, float* mixture, int B, int L,
+                    double* scratch, void* stream) {
+    if (!c || !source || !noise || !snr_db || !mixture || !scratch || B <= 0 || L <= 0)
+        return fail(c, LASS_ERR_ARG, "lass_mix_at_snr: bad argument");
+    HIP_TRY(c, lass_launch_mix_at_snr(source, noise, snr_db, mixture, B, L, scratch, (hipStream_t)stream));
+    return 0;
+}
+
 int lass_separate(lass_ctx* c, const float* mixture, const float* condition, float* out, int B, int L, void* workspace,
                   size_t workspace_bytes, void* stream) {
     int r = check_ready(c);

@@ -99,6 +99,10 @@ hipError_t lass_launch_mask(const float* x12, const float* wa, const float* ba, 
                             const float* sinv, int B, int T, int Tpad, float* out_real, float* out_imag,
                             hipStream_t stream);
 hipError_t lass_launch_sdr(const float* ref, const float* est, int B, int L, double* stats, hipStream_t stream);
+// mixture = source + noise * sqrt(P_source / 10^(snr/10) / P_noise); if max|mixture| > 1 both source and mixture are
+// scaled by 0.9/max (dcase_evaluator.py:77-89).  source is updated in place; ws: 4*B doubles of scratch.
+hipError_t lass_launch_mix_at_snr(float* source, const float* noise, const float* snr_db, float* mixture, int B, int L,
+                                  double* ws, hipStream_t stream);
 // dst[ci][tap][co] = src[co][ci][tap]
 hipError_t lass_launch_relayout_conv(const float* src, int Cout, int Cin, int taps, float* dst, hipStream_t stream);
 // scale[c] = g/sqrt(var+eps); base[c] = beta - mean*scale

@@ -169,6 +169,72 @@ __global__ __launch_bounds__(256) void sdr_pass2(const float* __restrict__ ref, 
     }
 }
 
+// ---- mixture creation at a given SNR + declipping (dcase_evaluator.py:77-89), device-resident ----------------------
+// pass 1: ws[b] = {sum source^2, sum noise^2, (max |mixture| as float bits), unused}
+__global__ __launch_bounds__(256) void mix_power_kernel(const float* __restrict__ src, const float* __restrict__ noise,
+                                                        int L, double* __restrict__ ws) {
+    __shared__ double red[4][2];
+    const int b = blockIdx.y;
+    const float* s = src + (size_t)b * L;
+    const float* n = noise + (size_t)b * L;
+    double s0 = 0, s1 = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < L; i += gridDim.x * 256) {
+        const double sv = s[i], nv = n[i];
+        s0 += sv * sv;
+        s1 += nv * nv;
+    }
+    s0 = wave_sum_d(s0); s1 = wave_sum_d(s1);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) { red[wv][0] = s0; red[wv][1] = s1; }
+    __syncthreads();
+    if (threadIdx.x < 2)
+        atomicAdd(&ws[(size_t)b * 4 + threadIdx.x],
+                  red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// noise scaling factor sqrt((P_source / 10^(snr/10)) / P_noise) (the 1/L of the two means cancels)
+__device__ __forceinline__ float mix_scale(const double* ws, int b, float snr_db) {
+    return (float)sqrt(ws[(size_t)b * 4] / pow(10.0, (double)snr_db / 10.0) / ws[(size_t)b * 4 + 1]);
+}
+
+// pass 2: mixture = source + noise * scale; per-clip max |mixture| (non-negative floats order like their bit patterns)
+__global__ __launch_bounds__(256) void mix_apply_kernel(const float* __restrict__ src, const float* __restrict__ noise,
+                                                        const float* __restrict__ snr_db, int L,
+                                                        double* __restrict__ ws, float* __restrict__ mix) {
+    __shared__ float red[4];
+    const int b = blockIdx.y;
+    const float sc = mix_scale(ws, b, snr_db[b]);
+    float mx = 0.f;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < L; i += gridDim.x * 256) {
+        const float nv = noise[(size_t)b * L + i] * sc;  // numpy: noise = noise * scaling_factor (f32), then the add
+        const float m = src[(size_t)b * L + i] + nv;
+        mix[(size_t)b * L + i] = m;
+        mx = fmaxf(mx, fabsf(m));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) red[wv] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        atomicMax(reinterpret_cast<unsigned int*>(&ws[(size_t)b * 4 + 2]), __float_as_uint(mx));
+    }
+}
+
+// pass 3: declipping - if max |mixture| > 1, source and mixture are both scaled by 0.9 / max (dcase_evaluator.py:86-89)
+__global__ __launch_bounds__(256) void mix_declip_kernel(float* __restrict__ src, float* __restrict__ mix, int L,
+                                                         const double* __restrict__ ws) {
+    const int b = blockIdx.y;
+    const float mx = __uint_as_float(*reinterpret_cast<const unsigned int*>(&ws[(size_t)b * 4 + 2]));
+    if (!(mx > 1.f)) return;
+    const float g = 0.9f / mx;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < L; i += gridDim.x * 256) {
+        src[(size_t)b * L + i] *= g;
+        mix[(size_t)b * L + i] *= g;
+    }
+}
+
 __global__ __launch_bounds__(256) void relayout_conv_kernel(const float* __restrict__ src, int Cout, int Cin, int taps,
                                                             float* __restrict__ dst) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;  // index into dst [ci][tap][co]
@@ -253,5 +319,18 @@ hipError_t lass_launch_bnfold(const float* g, const float* beta, const float* me
                               float* scale, float* base, hipStream_t stream) {
     hipLaunchKernelGGL(bnfold_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, g, beta, mean, var, C, eps, scale,
                        base);
+    return hipGetLastError();
+}
+
+hipError_t lass_launch_mix_at_snr(float* source, const float* noise, const float* snr_db, float* mixture, int B, int L,
+                                  double* ws, hipStream_t stream) {
+    if (B <= 0 || L <= 0) return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(ws, 0, sizeof(double) * 4 * B, stream);
+    if (e != hipSuccess) return e;
+    int nb = (L + 256 * 16 - 1) / (256 * 16);
+    if (nb > 64) nb = 64;
+    hipLaunchKernelGGL(mix_power_kernel, dim3(nb, B), dim3(256), 0, stream, source, noise, L, ws);
+    hipLaunchKernelGGL(mix_apply_kernel, dim3(nb, B), dim3(256), 0, stream, source, noise, snr_db, L, ws, mixture);
+    hipLaunchKernelGGL(mix_declip_kernel, dim3(nb, B), dim3(256), 0, stream, source, mixture, L, ws);
     return hipGetLastError();
 }

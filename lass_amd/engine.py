@@ -207,6 +207,19 @@ class Engine:
         _lib.check(self.ctx, rc, "lass_sdr_stats")
         return stats
 
+    def mix_at_snr(self, source: torch.Tensor, noise: torch.Tensor, snr_db: torch.Tensor):
+        """dcase_evaluator.py:77-89 on the device.  source (B,L) is scaled IN PLACE when the mixture needs declipping;
+        returns the mixture (B,L)."""
+        source, noise, snr_db = self._dev(source), self._dev(noise), self._dev(snr_db)
+        B, L = source.shape
+        assert noise.shape == source.shape and snr_db.shape == (B,)
+        mixture = torch.empty_like(source)
+        scratch = torch.empty(B, 4, dtype=torch.float64, device=self.device)
+        rc = self.lib.lass_mix_at_snr(self.ctx, _ptr(source), _ptr(noise), _ptr(snr_db), _ptr(mixture), B, L,
+                                      _ptr(scratch), _stream(self.device))
+        _lib.check(self.ctx, rc, "lass_mix_at_snr")
+        return mixture
+
     # ---- instrumentation -------------------------------------------------------------------------------------
     def set_profiling(self, on: bool):
         self.lib.lass_set_profiling(self.ctx, 1 if on else 0)

@@ -5,6 +5,10 @@ definitions and the same printed line.  Differences are in execution only:
   * clips are separated in batches (`batch_size`, default 16) instead of one by one - eval-mode BatchNorm has no
     cross-clip coupling, so results are unchanged;
   * SDR / SI-SDR reductions run on the device over the resident waveforms (no D2H of audio);
+  *  the SNR mixing / declipping runs on the device too (`lass_mix_at_snr`), WAV decoding of the next
+    clips is prefetched by a small thread pool while the GPU separates the current batch, and caption embeddings are
+    cached per caption (captions repeat; the query encoder is called once per distinct caption);
+    `device_mixing=False` restores the reference's host-side numpy mixing (used by the parity tests as the yardstick);
   * under torch.distributed the clip list is block-sharded over ranks and the per-clip metric rows are all-gathered
     once at the end (RCCL when the backend is "nccl").
 """
@@ -12,6 +16,8 @@ from __future__ import annotations
 
 import csv
 import os
+from collections import deque
+from concurrent.futures import ThreadPoolExecutor
 from typing import Dict, List
 
 import numpy as np
@@ -26,7 +32,7 @@ from .wavio import read_wav
 
 class DCASEEvaluator:
     def __init__(self, sampling_rate=16000, eval_indexes="lass_synthetic_validation.csv", audio_dir="lass_validation",
-                 batch_size: int = 16) -> None:
+                 batch_size: int = 16, device_mixing: bool = True, io_workers: int = 4) -> None:
         r"""DCASE T9 LASS evaluator (dcase_evaluator.py:28-47)."""
         self.sampling_rate = sampling_rate
         with open(eval_indexes) as csv_file:
@@ -35,7 +41,26 @@ class DCASEEvaluator:
         self.eval_list = eval_list
         self.audio_dir = audio_dir
         self.batch_size = batch_size
+        self.device_mixing = device_mixing
+        self.io_workers = max(1, io_workers)
         self.last_rows = None  # (N,3) per-clip [sdr, sdri, sisdr] of the last call (all ranks)
+        self._embed_cache: Dict[str, torch.Tensor] = {}
+
+    def _read_pair(self, eval_data):
+        """dcase_evaluator.py:67-74 for one csv row: decode the two clips only -> (source, noise, snr, caption)."""
+        source, noise, snr, caption = eval_data
+        source, _ = read_wav(os.path.join(self.audio_dir, f"{source}.wav"), self.sampling_rate)
+        noise, _ = read_wav(os.path.join(self.audio_dir, f"{noise}.wav"), self.sampling_rate)
+        return source.astype(np.float32, copy=False), noise.astype(np.float32, copy=False), int(snr), caption
+
+    def _conditions(self, pl_model, captions: List[str], device) -> torch.Tensor:
+        """One query-encoder call per DISTINCT caption not seen before (dcase_evaluator.py:93-97 calls it per clip)."""
+        missing = [c for c in dict.fromkeys(captions) if c not in self._embed_cache]
+        if missing:
+            emb = pl_model.query_encoder.get_query_embed(modality="text", text=missing, device=device)
+            for c, e in zip(missing, emb):
+                self._embed_cache[c] = e.detach().to(device=device, dtype=torch.float32)
+        return torch.stack([self._embed_cache[c] for c in captions])
 
     def _load_clip(self, eval_data):
         """dcase_evaluator.py:67-89 for one csv row -> (source, mixture, caption), float32."""
@@ -69,22 +94,40 @@ class DCASEEvaluator:
         n_total = len(self.eval_list)
         lo, hi = ldist.shard_range(n_total, rank, ws)
         rows: List[np.ndarray] = []
-        with torch.no_grad():
-            i = lo
-            while i < hi:
-                group = [self._load_clip(self.eval_list[i])]
-                i += 1
+        self._embed_cache.clear()  # embeddings belong to this pl_model's query encoder
+        loader = self._read_pair if self.device_mixing else self._load_clip
+        with torch.no_grad(), ThreadPoolExecutor(max_workers=self.io_workers) as pool:
+            # sliding window of decode jobs: at most two batches ahead of the one on the GPU
+            pending = deque()
+            nxt = lo
+
+            def refill():
+                nonlocal nxt
+                while nxt < hi and len(pending) < 2 * self.batch_size:
+                    pending.append(pool.submit(loader, self.eval_list[nxt]))
+                    nxt += 1
+
+            refill()
+            while pending:
+                group = [pending.popleft().result()]
                 # batch consecutive clips of identical length (DCASE clips are all 10 s)
-                while i < hi and len(group) < self.batch_size:
-                    nxt = self._load_clip(self.eval_list[i])
-                    if nxt[0].shape != group[0][0].shape:
+                while pending and len(group) < self.batch_size:
+                    cand = pending[0].result()
+                    if cand[0].shape != group[0][0].shape:
                         break
-                    group.append(nxt)
-                    i += 1
+                    group.append(cand)
+                    pending.popleft()
+                refill()
                 src = torch.from_numpy(np.stack([g[0] for g in group])).to(device)
-                mix = torch.from_numpy(np.stack([g[1] for g in group])).to(device)
-                conditions = pl_model.query_encoder.get_query_embed(modality="text", text=[g[2] for g in group],
-                                                                    device=device)
+                if self.device_mixing:
+                    noise = torch.from_numpy(np.stack([g[1] for g in group])).to(device)
+                    snr = torch.tensor([float(g[2]) for g in group], dtype=torch.float32, device=device)
+                    mix = eng.mix_at_snr(src, noise, snr)  # src is rescaled in place where the mixture clipped
+                    captions = [g[3] for g in group]
+                else:
+                    mix = torch.from_numpy(np.stack([g[1] for g in group])).to(device)
+                    captions = [g[2] for g in group]
+                conditions = self._conditions(pl_model, captions, device)
                 input_dict = {"mixture": mix[:, None, :], "condition": conditions}
                 sep = pl_model.ss_model(input_dict)["waveform"][:, 0, :]
                 length = src.shape[1]

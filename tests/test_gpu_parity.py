@@ -319,6 +319,45 @@ def test_evaluator_matches_oracle(tmp_path, model, oracle_sd):
     (o_sisdr, o_sdri, o_sdr), rows = oev.evaluate(oracle_sd, clips, conds)
     np.testing.assert_allclose(ev.last_rows, rows, atol=0.01)
     assert abs(sdr - o_sdr) < 0.01 and abs(sdri - o_sdri) < 0.01 and abs(sisdr - o_sisdr) < 0.01
+    # default path = device-side mixing + prefetch + caption cache; the reference's host-side numpy mixing must agree
+    calls = []
+    orig = qe.get_query_embed
+    qe.get_query_embed = lambda *a, **k: (calls.append(list(k.get("text") or a[1])), orig(*a, **k))[1]
+    host = DCASEEvaluator(sampling_rate=16000, eval_indexes=csv_path, audio_dir=os.path.join(str(tmp_path), "lass_validation"),
+                          batch_size=3, device_mixing=False)
+    assert host(pl_model) == pytest.approx((sisdr, sdri, sdr), abs=2e-3)
+    np.testing.assert_allclose(host.last_rows, ev.last_rows, atol=2e-3)
+    assert sorted(sum(calls, [])) == sorted({f"synthetic tone cluster {i}" for i in range(4)})  # once per caption
+
+
+def test_mix_at_snr_vs_reference_formula(eng):
+    """lass_mix_at_snr against dcase_evaluator.py:77-89 restated in numpy float32, incl. clips that need declipping."""
+    rng = np.random.default_rng(3)
+    B, L = 6, 48000
+    src = (rng.standard_normal((B, L)) * rng.uniform(0.02, 0.6, (B, 1))).astype(np.float32)
+    noise = (rng.standard_normal((B, L)) * rng.uniform(0.01, 0.5, (B, 1))).astype(np.float32)
+    snrs = np.array([-15, -10, 0, 5, 15, -15], dtype=np.float32)
+    src[5] *= 3.0  # loud source at -15 dB SNR: certainly clips
+    exp_src, exp_mix = [], []
+    for b in range(B):
+        s, n = src[b].copy(), noise[b]
+        sf = np.sqrt((np.mean(s ** 2) / (10 ** (float(snrs[b]) / 10))) / np.mean(n ** 2))
+        m = s + n * np.float32(sf)
+        mx = np.max(np.abs(m))
+        if mx > 1:
+            s *= np.float32(0.9 / mx)
+            m *= np.float32(0.9 / mx)
+        exp_src.append(s)
+        exp_mix.append(m)
+    d_src = torch.from_numpy(src).to(DEV)
+    mix = eng.mix_at_snr(d_src, torch.from_numpy(noise).to(DEV), torch.from_numpy(snrs).to(DEV)).cpu().numpy()
+    got_src = d_src.cpu().numpy()
+    clipped = [float(np.max(np.abs(m))) for m in exp_mix]
+    assert any(abs(c - 0.9) < 1e-5 for c in clipped) and any(c < 0.9 for c in clipped)  # both branches exercised
+    for b in range(B):
+        scale = float(np.max(np.abs(exp_mix[b])))
+        assert float(np.max(np.abs(mix[b] - exp_mix[b]))) < 2e-6 * max(scale, 1.0)
+        assert float(np.max(np.abs(got_src[b] - exp_src[b]))) < 2e-6 * max(scale, 1.0)
 
 
 # ---- BASELINE configs[2]: bf16-MFMA convolutions (reduced precision by design; its own tolerances) --------------------
