@@ -309,12 +309,12 @@ int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int
     }
     p.w_wino = rb.u1;
     p.w_bf16 = rb.b1; p.w_bf16_lo = rb.b1l;
-    const bool bf1 = c->compute_mode != LASS_COMPUTE_F32 && !x0 && rb.b1 && lass_bf16_supported(p);
+    const bool bf1 = c->compute_mode != LASS_COMPUTE_F32 && rb.b1 && lass_bf16_supported(p) && (!x0 || W % 32 == 0);
     const bool wino1 = !bf1 && c->wino && rb.u1 && lass_wino_supported(p);
     {
         ProfScope ps(c, st, P_CONV3X3);
         if (bf1)
-            HIP_TRY(c, lass_launch_conv_bf16(CONV1_ACT, p, st));
+            HIP_TRY(c, lass_launch_conv_bf16(x0 ? CONV1_ACT_PRE : CONV1_ACT, p, st));
         else if (wino1)
             HIP_TRY(c, lass_launch_wino(x0 ? CONV1_ACT_PRE : CONV1_ACT, p, st));
         else
@@ -326,7 +326,7 @@ int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int
     q.pool_out = pool_out; q.pool_h = pool_h;
     q.w_wino = rb.u2; q.w2_wino = rb.usc;
     q.w_bf16 = rb.b2; q.w2_bf16 = rb.bsc16; q.w_bf16_lo = rb.b2l; q.w2_bf16_lo = rb.bscl;
-    const bool bf2 = c->compute_mode != LASS_COMPUTE_F32 && !x0 && rb.b2 && lass_bf16_supported(q) &&
+    const bool bf2 = c->compute_mode != LASS_COMPUTE_F32 && rb.b2 && lass_bf16_supported(q) && (!x0 || W % 32 == 0) &&
                      (rb.cin == rb.cout || (rb.bsc16 && rb.cin % 16 == 0));
     const bool wino2 = !bf2 && c->wino && rb.u2 && lass_wino_supported(q);
     ProfScope ps(c, st, P_CONV3X3);
@@ -337,7 +337,7 @@ int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int
             q.pre_w = rawp(c, "base.pre_conv.weight"); q.pre_b = rawp(c, "base.pre_conv.bias");
         }
         if (bf2)
-            HIP_TRY(c, lass_launch_conv_bf16(CONV2_IDENT, q, st));
+            HIP_TRY(c, lass_launch_conv_bf16(x0 ? CONV2_IDENT_PRE : CONV2_IDENT, q, st));
         else if (wino2)
             HIP_TRY(c, lass_launch_wino(x0 ? CONV2_IDENT_PRE : CONV2_IDENT, q, st));
         else
@@ -813,7 +813,7 @@ int lass_separate(lass_ctx* c, const float* mixture, const float* condition, flo
         HIP_TRY(c, lass_launch_film(condition, B, c->film_W, c->film_b, c->bn_base, c->n_shift, shift, st));
     }
     // pre_conv (resunet.py:555) is normally never materialised: encoder_block1 forms it from x0 while staging
-    const bool fuse_pre = c->fuse_preconv && c->compute_mode == LASS_COMPUTE_F32;  // bf16 kernels read a materialised input
+    const bool fuse_pre = c->fuse_preconv;
     if (!fuse_pre) {
         ProfScope ps(c, st, P_PRECONV);
         HIP_TRY(c, lass_launch_preconv(F(pl.x0), rawp(c, "base.pre_conv.weight"), rawp(c, "base.pre_conv.bias"), B,

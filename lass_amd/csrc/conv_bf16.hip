@@ -22,7 +22,9 @@ constexpr int KB = 16;  // input channels per chunk
 
 // SPLIT = 1: operands rounded to bf16.  SPLIT = 2: every f32 operand is split x = hi + lo (two bf16) and the product is
 // formed as hi*hi + hi*lo + lo*hi (three MFMAs, f32 accumulate): ~16 mantissa bits per operand, error ~2^-17 per product.
-template <int TAPS, int NCO, int NPX, int PW, bool PRO, int SPLIT>
+// PRE: the input is the single-channel x0; channel c = pre_w[c]*x0 + pre_b[c] (pre_conv, resunet.py:555) is formed while
+// staging, so a chunk needs no activation loads at all (x0 at this thread's pixels is fetched once per tile).
+template <int TAPS, int NCO, int NPX, int PW, bool PRO, int SPLIT, bool PRE = false>
 struct Phase16 {
     static constexpr int PH = 32 / PW;
     static constexpr int WROWS = NPX * PH;
@@ -43,7 +45,9 @@ struct Phase16 {
     unsigned goff[NPP];  // BYTE offset of this thread's pixel inside a channel plane (32-bit lane part of a buffer address)
     unsigned woff[NWLD]; // BYTE offset of this thread's 16-B weight units inside a chunk's slab
     unsigned okbits;
-    float v[2][NPP][8];  // prefetched f32 activations: [octet][pass][channel in octet]
+    float v[PRE ? 1 : 2][PRE ? 1 : NPP][PRE ? 1 : 8];  // prefetched f32 activations: [octet][pass][channel in octet]
+    float x0v[PRE ? NPP : 1];        // PRE: x0 at this thread's pixels
+    float pcw[PRE ? KB : 1], pcb[PRE ? KB : 1];  // PRE: pre_conv weight / bias of the prefetched chunk's channels
     uint4 wv[SPLIT][NWLD];  // prefetched bf16 weights (hi, lo)
     float psc[KB], psh[KB];
 
@@ -77,15 +81,25 @@ struct Phase16 {
     // (hi / lo) from column n0 on, wb = byte offset of the chunk's slab [tap][octet][Cout].
     __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t in_rs, unsigned c0b, int HW, __amdgpu_buffer_rsrc_t w_rs,
                                          __amdgpu_buffer_rsrc_t wl_rs, unsigned wb, const float* __restrict__ sc,
-                                         const float* __restrict__ sh) {
+                                         const float* __restrict__ sh, const float* __restrict__ pw = nullptr,
+                                         const float* __restrict__ pb = nullptr) {
+        if (!PRE) {
 #pragma unroll
-        for (int o = 0; o < 2; ++o)
+            for (int o = 0; o < 2; ++o)
 #pragma unroll
-            for (int k = 0; k < NPP; ++k)
+                for (int k = 0; k < NPP; ++k)
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    v[o][k][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                               in_rs, (int)goff[k], (int)(c0b + (unsigned)((o * 8 + j) * HW) * 4u), 0));
+                    for (int j = 0; j < 8; ++j)
+                        v[o][k][j] = __builtin_bit_cast(
+                            float, __builtin_amdgcn_raw_buffer_load_b32(in_rs, (int)goff[k],
+                                                                        (int)(c0b + (unsigned)((o * 8 + j) * HW) * 4u), 0));
+        } else {
+#pragma unroll
+            for (int c = 0; c < KB; ++c) {
+                pcw[c] = pw[c];
+                pcb[c] = pb[c];
+            }
+        }
 #pragma unroll
         for (int i = 0; i < NWLD; ++i) {
             wv[0][i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(w_rs, (int)woff[i], (int)wb, 0));
@@ -100,6 +114,11 @@ struct Phase16 {
             }
         }
     }
+    __device__ __forceinline__ void load_x0(__amdgpu_buffer_rsrc_t in_rs) {  // PRE only: once per tile
+#pragma unroll
+        for (int k = 0; k < NPP; ++k)
+            x0v[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rs, (int)goff[k], 0, 0));
+    }
     __device__ __forceinline__ void store(uint4* lds, int tid) {
 #pragma unroll
         for (int o = 0; o < 2; ++o)
@@ -110,7 +129,7 @@ struct Phase16 {
                 bf16x8 pk, pl;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    float t = v[o][k][j];
+                    float t = PRE ? x0v[k] * pcw[o * 8 + j] + pcb[o * 8 + j] : v[PRE ? 0 : o][PRE ? 0 : k][PRE ? 0 : j];
                     if (PRO) t = leaky(t * psc[o * 8 + j] + psh[o * 8 + j]);
                     t = ok ? t : 0.f;  // conv zero padding comes after the activation
                     pk[j] = (__bf16)t;
@@ -195,7 +214,10 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
     constexpr bool BIAS = (FLAGS & F_BIAS) != 0;
     constexpr bool RES = (FLAGS & F_RES) != 0;
     constexpr bool RES_PF = RES && NCO == 1;
-    using PA = Phase16<TAPS, NCO, NPX, PW, PRO, SPLIT>;
+    constexpr bool PRE = (FLAGS & F_PRECONV) != 0;
+    constexpr bool RESPRE = (FLAGS & F_RESPRE) != 0;
+    static_assert(!RESPRE || RES_PF, "x0-derived residual needs the register-prefetch path");
+    using PA = Phase16<TAPS, NCO, NPX, PW, PRO, SPLIT, PRE>;
     using PB = Phase16<1, NCO, NPX, PW, false, SPLIT>;
     constexpr int LDS_U4 = HASB ? MaxU<PA::LDS_U4, PB::LDS_U4>::v : PA::LDS_U4;
     constexpr int PH = PA::PH, WROWS = PA::WROWS, PHT = PA::PHT, NT = PA::NT;
@@ -239,7 +261,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
     const auto rs = [](const void* ptr, long bytes) {
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, (int)bytes, 0x00020000);
     };
-    const __amdgpu_buffer_rsrc_t in_rs = rs(in_b, (long)p.Cin * HW * 4);
+    const __amdgpu_buffer_rsrc_t in_rs = rs(in_b, (long)(PRE ? 1 : p.Cin) * HW * 4);
     const __amdgpu_buffer_rsrc_t wa_rs = rs(wa, ((long)(p.Cin / KB) * TAPS * 2 * p.Nw - n0) * 16);
     const __amdgpu_buffer_rsrc_t wal_rs = SPLIT == 2 ? rs(wa_lo, ((long)(p.Cin / KB) * TAPS * 2 * p.Nw - n0) * 16) : wa_rs;
     const __amdgpu_buffer_rsrc_t in2_rs = HASB ? rs(in2_b, (long)p.Cin2 * HW * 4) : in_rs;
@@ -247,7 +269,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
     const __amdgpu_buffer_rsrc_t wbl_rs = (HASB && SPLIT == 2) ? rs(wb2_lo, ((long)(p.Cin2 / KB) * 2 * p.Nw - n0) * 16) : wb_rs;
     auto loadA = [&](int c) {
         pa.load(in_rs, (unsigned)(c * KB * HW) * 4u, HW, wa_rs, wal_rs, (unsigned)(c * TAPS * 2 * p.Nw) * 16u, sc + c * KB,
-                sh + c * KB);
+                sh + c * KB, PRE ? p.pre_w + c * KB : nullptr, PRE ? p.pre_b + c * KB : nullptr);
     };
     auto loadB = [&](int c) {
         pb.load(in2_rs, (unsigned)(c * KB * HW) * 4u, HW, wb_rs, wbl_rs, (unsigned)(c * 2 * p.Nw) * 16u, nullptr, nullptr);
@@ -255,6 +277,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
 
     pa.init(tid, y0, x0, p.H, p.W);
     pa.init_w(tid, p.Nw);
+    if (PRE) pa.load_x0(in_rs);
     loadA(0);
     __syncthreads();
     pa.store(lds4, tid);
@@ -286,9 +309,18 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
 #pragma unroll
         for (int px = 0; px < NPX; ++px) {
             const int y = min(y0 + wave * WROWS + px * PH + ty, p.H - 1);
-            const float* src = p.res + (size_t)b * p.res_bs + (size_t)(n0 + 4 * khalf) * HW + (size_t)y * p.W + x;
+            if (RESPRE) {  // residual = pre_conv(x0) at this pixel: one load, 16 FMAs (resunet.py:555,165)
+                const float xv = p.res[(size_t)b * p.res_bs + (size_t)y * p.W + x];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) rtmp[px][r] = src[(size_t)((r & 3) + 8 * (r >> 2)) * HW];
+                for (int r = 0; r < 16; ++r) {
+                    const int n = n0 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                    rtmp[px][r] = xv * p.pre_w[n] + p.pre_b[n];
+                }
+            } else {
+                const float* src = p.res + (size_t)b * p.res_bs + (size_t)(n0 + 4 * khalf) * HW + (size_t)y * p.W + x;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rtmp[px][r] = src[(size_t)((r & 3) + 8 * (r >> 2)) * HW];
+            }
         }
     }
     PA::compute(lds4, acc, lane, wave);
@@ -376,6 +408,14 @@ hipError_t lass_launch_conv_bf16(ConvKind kind, const ConvArgs& p, hipStream_t s
         case TCONV_ACT:
             if (!p.pro_scale || !p.pro_shift || (p.up_h != 1 && p.up_h != 2)) return hipErrorInvalidValue;
             return launch_bf16<1, F_PRO | F_TCONV>(p, stream);
+        case CONV1_ACT_PRE:  // encoder_block1 at full resolution: 32 -> 32 channels, W a multiple of 32
+            if (!p.pro_scale || !p.pro_shift || !p.epi_scale || !p.epi_shift || !p.pre_w || !p.pre_b || p.N != 32 ||
+                p.Cin != 32 || p.W % 32 != 0)
+                return hipErrorInvalidValue;
+            return launch_bf16_one<9, 1, 2, 32, F_PRO | F_EPIACT | F_PRECONV>(p, stream);
+        case CONV2_IDENT_PRE:
+            if (!p.res || !p.pre_w || !p.pre_b || p.N != 32 || p.W % 32 != 0) return hipErrorInvalidValue;
+            return launch_bf16_one<9, 1, 2, 32, F_RES | F_RESPRE>(p, stream);
         default:
             return hipErrorInvalidValue;
     }
