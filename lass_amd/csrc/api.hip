@@ -309,7 +309,12 @@ int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int
     }
     p.w_wino = rb.u1;
     p.w_bf16 = rb.b1; p.w_bf16_lo = rb.b1l;
-    const bool bf1 = c->compute_mode != LASS_COMPUTE_F32 && rb.b1 && lass_bf16_supported(p) && (!x0 || W % 32 == 0);
+    const bool bf1 = c->compute_mode != LASS_COMPUTE_F32 && rb.b1 && rb.b2 && lass_bf16_supported(p) &&
+                     (!x0 || W % 32 == 0) && rb.cout % 16 == 0 && (rb.cin == rb.cout || (rb.bsc16 && rb.cin % 16 == 0));
+    // bf16 modes: the intermediate a2 is kept as blocked bf16 (hi, and lo for the split mode) in the same scratch
+    void* a2_hi = a2;
+    void* a2_lo = c->compute_mode == LASS_COMPUTE_BF16X3 ? (void*)((char*)a2 + (size_t)B * rb.cout * HW * 2) : nullptr;
+    if (bf1) { p.out_bf16 = a2_hi; p.out_bf16_lo = a2_lo; }
     const bool wino1 = !bf1 && c->wino && rb.u1 && lass_wino_supported(p);
     {
         ProfScope ps(c, st, P_CONV3X3);
@@ -326,8 +331,8 @@ int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int
     q.pool_out = pool_out; q.pool_h = pool_h;
     q.w_wino = rb.u2; q.w2_wino = rb.usc;
     q.w_bf16 = rb.b2; q.w2_bf16 = rb.bsc16; q.w_bf16_lo = rb.b2l; q.w2_bf16_lo = rb.bscl;
-    const bool bf2 = c->compute_mode != LASS_COMPUTE_F32 && rb.b2 && lass_bf16_supported(q) && (!x0 || W % 32 == 0) &&
-                     (rb.cin == rb.cout || (rb.bsc16 && rb.cin % 16 == 0));
+    const bool bf2 = bf1;  // conv1 and conv2 of a block share shape and mode: both or neither
+    if (bf2) { q.in_bf16 = a2_hi; q.in_bf16_lo = a2_lo; }
     const bool wino2 = !bf2 && c->wino && rb.u2 && lass_wino_supported(q);
     ProfScope ps(c, st, P_CONV3X3);
     if (rb.cin == rb.cout) {

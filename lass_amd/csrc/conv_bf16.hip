@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include "conv_common.h"
 #include "kernels.h"
+#include "wino_common.h"  // make_rsrc_words, lds_dma_16B, wait_vmcnt
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -24,7 +25,10 @@ constexpr int KB = 16;  // input channels per chunk
 // formed as hi*hi + hi*lo + lo*hi (three MFMAs, f32 accumulate): ~16 mantissa bits per operand, error ~2^-17 per product.
 // PRE: the input is the single-channel x0; channel c = pre_w[c]*x0 + pre_b[c] (pre_conv, resunet.py:555) is formed while
 // staging, so a chunk needs no activation loads at all (x0 at this thread's pixels is fetched once per tile).
-template <int TAPS, int NCO, int NPX, int PW, bool PRO, int SPLIT, bool PRE = false>
+// DMA: the input is the block's bf16 intermediate in the blocked layout [C/8][H][W][8 x bf16] (16-B units; written by
+// conv1's epilogue, lo plane separately for SPLIT = 2): staging is a pure copy, done by LDS-DMA with per-lane unit offsets
+// (out-of-image units get an out-of-range offset: the buffer bounds check returns the zero padding) - no VGPRs, no VALU.
+template <int TAPS, int NCO, int NPX, int PW, bool PRO, int SPLIT, bool PRE = false, bool DMA = false>
 struct Phase16 {
     static constexpr int PH = 32 / PW;
     static constexpr int WROWS = NPX * PH;
@@ -35,6 +39,8 @@ struct Phase16 {
     static constexpr int NT = 32 * NCO;
     static constexpr int NPIX = IR * IP;
     static constexpr int NPP = (NPIX + NTHREADS - 1) / NTHREADS;  // pixel passes (each thread: one pixel, 8 channels)
+    static constexpr int NPIECE = (2 * NPIX + 63) / 64;           // DMA: 1-KiB pieces (64 units) per plane
+    static constexpr int NPC = (NPIECE + 3) / 4;                  // DMA: pieces per wave
     static constexpr int IN1_U4 = 2 * NPIX;                       // 16-byte units, one plane (hi or lo)
     static constexpr int W1_U4 = TAPS * 2 * NT;
     static constexpr int IN_U4 = SPLIT * IN1_U4;
@@ -45,7 +51,8 @@ struct Phase16 {
     unsigned goff[NPP];  // BYTE offset of this thread's pixel inside a channel plane (32-bit lane part of a buffer address)
     unsigned woff[NWLD]; // BYTE offset of this thread's 16-B weight units inside a chunk's slab
     unsigned okbits;
-    float v[PRE ? 1 : 2][PRE ? 1 : NPP][PRE ? 1 : 8];  // prefetched f32 activations: [octet][pass][channel in octet]
+    unsigned dvo[DMA ? NPC : 1];  // DMA: byte offset of this lane's unit in piece wave + 4*i (0xC0000000 = zero fill)
+    float v[(PRE || DMA) ? 1 : 2][(PRE || DMA) ? 1 : NPP][(PRE || DMA) ? 1 : 8];  // prefetched f32 activations: [octet][pass][channel in octet]
     float x0v[PRE ? NPP : 1];        // PRE: x0 at this thread's pixels
     float pcw[PRE ? KB : 1], pcb[PRE ? KB : 1];  // PRE: pre_conv weight / bias of the prefetched chunk's channels
     uint4 wv[SPLIT][NWLD];  // prefetched bf16 weights (hi, lo)
@@ -76,6 +83,32 @@ struct Phase16 {
             woff[i] = 16u * (unsigned)(row * Cout + col);
         }
     }
+    __device__ __forceinline__ void init_dma(int lane, int wave, int y0, int x0, int H, int W) {
+#pragma unroll
+        for (int i = 0; i < NPC; ++i) {
+            const int e = (wave + 4 * i) * 64 + lane;  // unit index in the [octet][NPIX] image
+            const int o = e / NPIX, u = e % NPIX;
+            const int r = u / IP, x = u % IP;
+            const int gy = y0 + r - HALO, gx = x0 + x - HALO;
+            const bool ok = e < 2 * NPIX && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            // 0xC0000000: beyond any descriptor -> zero fill (padding); 0xFFFFFFFF: lane past the image -> not issued
+            dvo[i] = ok ? 16u * (unsigned)((o * H + gy) * W + gx) : (e < 2 * NPIX ? 0xC0000000u : 0xFFFFFFFFu);
+        }
+    }
+    // rs / rs_lo: descriptors of this clip's blocked bf16 planes; soff: byte offset of the chunk's first octet;
+    // img: LDS byte address of the image buffer to fill
+    __device__ __forceinline__ void issue_dma(v4i32 rs, v4i32 rs_lo, unsigned soff, unsigned img, int wave) {
+#pragma unroll
+        for (int i = 0; i < NPC; ++i) {
+            const int piece = wave + 4 * i;
+            // the last piece of a plane is partial: its surplus lanes are masked off (an LDS-DMA lane that is not
+            // executed writes nothing), so the image needs no padding behind it
+            if (piece < NPIECE && dvo[i] != 0xFFFFFFFFu) {
+                lds_dma_16B(rs, dvo[i], soff, img + (unsigned)piece * 1024u);
+                if (SPLIT == 2) lds_dma_16B(rs_lo, dvo[i], soff, img + (unsigned)(IN1_U4 * 16) + (unsigned)piece * 1024u);
+            }
+        }
+    }
     // Buffer-addressed loads (descriptor + scalar byte offset + constant 32-bit lane offset: no VALU address arithmetic).
     // in_rs: this clip's input planes, c0b = byte offset of the chunk's first channel; w_rs / wl_rs: the weight matrix
     // (hi / lo) from column n0 on, wb = byte offset of the chunk's slab [tap][octet][Cout].
@@ -83,7 +116,7 @@ struct Phase16 {
                                          __amdgpu_buffer_rsrc_t wl_rs, unsigned wb, const float* __restrict__ sc,
                                          const float* __restrict__ sh, const float* __restrict__ pw = nullptr,
                                          const float* __restrict__ pb = nullptr) {
-        if (!PRE) {
+        if (!PRE && !DMA) {
 #pragma unroll
             for (int o = 0; o < 2; ++o)
 #pragma unroll
@@ -93,7 +126,7 @@ struct Phase16 {
                         v[o][k][j] = __builtin_bit_cast(
                             float, __builtin_amdgcn_raw_buffer_load_b32(in_rs, (int)goff[k],
                                                                         (int)(c0b + (unsigned)((o * 8 + j) * HW) * 4u), 0));
-        } else {
+        } else if (PRE) {
 #pragma unroll
             for (int c = 0; c < KB; ++c) {
                 pcw[c] = pw[c];
@@ -119,9 +152,10 @@ struct Phase16 {
         for (int k = 0; k < NPP; ++k)
             x0v[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rs, (int)goff[k], 0, 0));
     }
-    __device__ __forceinline__ void store(uint4* lds, int tid) {
+    // lds: image buffer (non-DMA); wl: weight region
+    __device__ __forceinline__ void store(uint4* lds, uint4* wl, int tid) {
 #pragma unroll
-        for (int o = 0; o < 2; ++o)
+        for (int o = 0; o < (DMA ? 0 : 2); ++o)
 #pragma unroll
             for (int k = 0; k < NPP; ++k) {
                 const int u = upos(tid, k);
@@ -129,7 +163,8 @@ struct Phase16 {
                 bf16x8 pk, pl;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    float t = PRE ? x0v[k] * pcw[o * 8 + j] + pcb[o * 8 + j] : v[PRE ? 0 : o][PRE ? 0 : k][PRE ? 0 : j];
+                    float t = PRE ? x0v[k] * pcw[o * 8 + j] + pcb[o * 8 + j]
+                                  : v[(PRE || DMA) ? 0 : o][(PRE || DMA) ? 0 : k][(PRE || DMA) ? 0 : j];
                     if (PRO) t = leaky(t * psc[o * 8 + j] + psh[o * 8 + j]);
                     t = ok ? t : 0.f;  // conv zero padding comes after the activation
                     pk[j] = (__bf16)t;
@@ -142,15 +177,16 @@ struct Phase16 {
         for (int i = 0; i < NWLD; ++i) {
             const int e0 = tid + i * NTHREADS;
             const int e = e0 < W1_U4 ? e0 : W1_U4 - 1;
-            lds[IN_U4 + e] = wv[0][i];
-            if (SPLIT == 2) lds[IN_U4 + W1_U4 + e] = wv[1][i];
+            wl[e] = wv[0][i];
+            if (SPLIT == 2) wl[W1_U4 + e] = wv[1][i];
         }
     }
-    __device__ __forceinline__ static void compute(const uint4* lds, f32x16 (&acc)[NCO][NPX], int lane, int wave) {
+    __device__ __forceinline__ static void compute(const uint4* lds, const uint4* wl, f32x16 (&acc)[NCO][NPX], int lane,
+                                                   int wave) {
         const int h = lane >> 5, j = lane & 31;
         const int ty = j / PW, tx = j % PW;
         const bf16x8* bbase = reinterpret_cast<const bf16x8*>(lds) + h * NPIX + (wave * WROWS + ty) * IP + tx;
-        const bf16x8* abase = reinterpret_cast<const bf16x8*>(lds) + IN_U4 + h * NT + j;
+        const bf16x8* abase = reinterpret_cast<const bf16x8*>(wl) + h * NT + j;
         if (SPLIT == 2) {
 #pragma unroll
             for (int tap = 0; tap < TAPS; ++tap) {
@@ -217,9 +253,11 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
     constexpr bool PRE = (FLAGS & F_PRECONV) != 0;
     constexpr bool RESPRE = (FLAGS & F_RESPRE) != 0;
     static_assert(!RESPRE || RES_PF, "x0-derived residual needs the register-prefetch path");
-    using PA = Phase16<TAPS, NCO, NPX, PW, PRO, SPLIT, PRE>;
+    constexpr bool INBF = (FLAGS & F_INBF16) != 0;    // phase A reads the blocked bf16 intermediate by LDS-DMA
+    using PA = Phase16<TAPS, NCO, NPX, PW, PRO, SPLIT, PRE, INBF>;
     using PB = Phase16<1, NCO, NPX, PW, false, SPLIT>;
-    constexpr int LDS_U4 = HASB ? MaxU<PA::LDS_U4, PB::LDS_U4>::v : PA::LDS_U4;
+    constexpr int PA_LDS = INBF ? 2 * PA::IN_U4 + PA::W_U4 : PA::LDS_U4;  // INBF: two image buffers + one weight region
+    constexpr int LDS_U4 = HASB ? MaxU<PA_LDS, PB::LDS_U4>::v : PA_LDS;
     constexpr int PH = PA::PH, WROWS = PA::WROWS, PHT = PA::PHT, NT = PA::NT;
     constexpr int NTAB = (EPI ? 2 * NT : 0) + (BIAS ? NT : 0);
 
@@ -230,7 +268,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
     float* lds_bias = tabs + (EPI ? 2 * NT : 0);
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.z;
     const int n0 = blockIdx.y * NT;
     const int tiles_x = p.W / PW;
@@ -241,7 +279,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
     const int x = x0 + tx;
     const int nA = p.Cin / KB;
     const int nB = HASB ? p.Cin2 / KB : 0;
-    const float* in_b = p.in + (size_t)b * p.in_bs;
+    const float* in_b = INBF ? nullptr : p.in + (size_t)b * p.in_bs;
     const float* in2_b = HASB ? p.in2 + (size_t)b * p.in2_bs : nullptr;
     const float* sc = PRO ? p.pro_scale : nullptr;
     const float* sh = PRO ? p.pro_shift + (size_t)b * p.pro_shift_bs : nullptr;
@@ -261,7 +299,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
     const auto rs = [](const void* ptr, long bytes) {
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, (int)bytes, 0x00020000);
     };
-    const __amdgpu_buffer_rsrc_t in_rs = rs(in_b, (long)(PRE ? 1 : p.Cin) * HW * 4);
+    const __amdgpu_buffer_rsrc_t in_rs = rs(in_b, INBF ? 0 : (long)(PRE ? 1 : p.Cin) * HW * 4);
     const __amdgpu_buffer_rsrc_t wa_rs = rs(wa, ((long)(p.Cin / KB) * TAPS * 2 * p.Nw - n0) * 16);
     const __amdgpu_buffer_rsrc_t wal_rs = SPLIT == 2 ? rs(wa_lo, ((long)(p.Cin / KB) * TAPS * 2 * p.Nw - n0) * 16) : wa_rs;
     const __amdgpu_buffer_rsrc_t in2_rs = HASB ? rs(in2_b, (long)p.Cin2 * HW * 4) : in_rs;
@@ -275,29 +313,65 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
         pb.load(in2_rs, (unsigned)(c * KB * HW) * 4u, HW, wb_rs, wbl_rs, (unsigned)(c * 2 * p.Nw) * 16u, nullptr, nullptr);
     };
 
-    pa.init(tid, y0, x0, p.H, p.W);
+    uint4* wl_a = lds4 + (INBF ? 2 * PA::IN_U4 : PA::IN_U4);  // weight region of phase A
     pa.init_w(tid, p.Nw);
-    if (PRE) pa.load_x0(in_rs);
-    loadA(0);
-    __syncthreads();
-    pa.store(lds4, tid);
-    __syncthreads();
-
     f32x16 acc[NCO][NPX];
+    auto init_acc = [&]() {
 #pragma unroll
-    for (int co = 0; co < NCO; ++co)
+        for (int co = 0; co < NCO; ++co)
 #pragma unroll
-        for (int px = 0; px < NPX; ++px)
+            for (int px = 0; px < NPX; ++px)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                acc[co][px][r] = BIAS ? lds_bias[co * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf] : 0.f;
-
-    for (int ch = 0; ch + 1 < nA; ++ch) {
-        loadA(ch + 1);
-        PA::compute(lds4, acc, lane, wave);
+                for (int r = 0; r < 16; ++r)
+                    acc[co][px][r] = BIAS ? lds_bias[co * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf] : 0.f;
+    };
+    if (INBF) {
+        // image of chunk ch+1 lands in the other buffer by LDS-DMA while chunk ch is contracted; weights go through
+        // registers into the single weight region between the two barriers
+        const long plane = (long)(p.Cin / 8) * HW * 16;  // bytes of one clip in the blocked layout
+        const v4i32 a_rs = make_rsrc_words(reinterpret_cast<const char*>(p.in_bf16) + (size_t)b * plane, (unsigned)plane);
+        const v4i32 al_rs = SPLIT == 2
+                                ? make_rsrc_words(reinterpret_cast<const char*>(p.in_bf16_lo) + (size_t)b * plane, (unsigned)plane)
+                                : a_rs;
+        const unsigned img0 = (unsigned)(size_t)(__attribute__((address_space(3))) uint4*)lds4;
+        const unsigned img1 = img0 + (unsigned)(PA::IN_U4 * 16);
+        pa.init_dma(lane, wave, y0, x0, p.H, p.W);
+        pa.issue_dma(a_rs, al_rs, 0u, img0, wave);
+        loadA(0);
+        __syncthreads();  // epilogue tables visible
+        pa.store(lds4, wl_a, tid);
+        wait_vmcnt<0>();
         __syncthreads();
-        pa.store(lds4, tid);
+        init_acc();
+        for (int ch = 0; ch < nA; ++ch) {
+            const bool more = ch + 1 < nA;
+            if (more) {
+                pa.issue_dma(a_rs, al_rs, (unsigned)((ch + 1) * 2 * HW) * 16u, (ch & 1) ? img0 : img1, wave);
+                loadA(ch + 1);
+            }
+            PA::compute(lds4 + ((ch & 1) ? PA::IN_U4 : 0), wl_a, acc, lane, wave);
+            __syncthreads();
+            if (more) {
+                pa.store(lds4, wl_a, tid);
+                wait_vmcnt<0>();
+            }
+            __syncthreads();
+        }
+    } else {
+        pa.init(tid, y0, x0, p.H, p.W);
+        if (PRE) pa.load_x0(in_rs);
+        loadA(0);
         __syncthreads();
+        pa.store(lds4, wl_a, tid);
+        __syncthreads();
+        init_acc();
+        for (int ch = 0; ch + 1 < nA; ++ch) {
+            loadA(ch + 1);
+            PA::compute(lds4, wl_a, acc, lane, wave);
+            __syncthreads();
+            pa.store(lds4, wl_a, tid);
+            __syncthreads();
+        }
     }
     float rtmp[RES_PF ? NPX : 1][16];
     if (HASB) {
@@ -323,19 +397,20 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
             }
         }
     }
-    PA::compute(lds4, acc, lane, wave);
+    if (!INBF) PA::compute(lds4, wl_a, acc, lane, wave);  // last chunk of phase A (the INBF loop contracts all of them)
     if (HASB) {
+        uint4* wl_b = lds4 + PB::IN_U4;
         __syncthreads();
-        pb.store(lds4, tid);
+        pb.store(lds4, wl_b, tid);
         __syncthreads();
         for (int ch = 0; ch + 1 < nB; ++ch) {
             loadB(ch + 1);
-            PB::compute(lds4, acc, lane, wave);
+            PB::compute(lds4, wl_b, acc, lane, wave);
             __syncthreads();
-            pb.store(lds4, tid);
+            pb.store(lds4, wl_b, tid);
             __syncthreads();
         }
-        PB::compute(lds4, acc, lane, wave);
+        PB::compute(lds4, wl_b, acc, lane, wave);
     }
     if (FLAGS & F_TCONV)
         tconv_store<NCO, NPX, PW>(p, acc, b, n0, y0, x0, lane, wave);
@@ -393,17 +468,22 @@ bool lass_bf16_supported(const ConvArgs& p) {
 }
 
 hipError_t lass_launch_conv_bf16(ConvKind kind, const ConvArgs& p, hipStream_t stream) {
-    if (!lass_bf16_supported(p) || !p.w_bf16 || !p.in || !p.out) return hipErrorInvalidValue;
+    if (!lass_bf16_supported(p) || !p.w_bf16 || (!p.in && !p.in_bf16) || (!p.out && !p.out_bf16)) return hipErrorInvalidValue;
+    if ((p.in_bf16 || p.out_bf16) && (p.Cin % 8 != 0 || p.N % 8 != 0)) return hipErrorInvalidValue;
+    if (p.w_bf16_lo && ((p.in_bf16 && !p.in_bf16_lo) || (p.out_bf16 && !p.out_bf16_lo))) return hipErrorInvalidValue;
     switch (kind) {
         case CONV1_ACT:
             if (!p.pro_scale || !p.pro_shift || !p.epi_scale || !p.epi_shift) return hipErrorInvalidValue;
+            if (p.out_bf16) return launch_bf16<9, F_PRO | F_EPIACT | F_OUTBF16>(p, stream);
             return launch_bf16<9, F_PRO | F_EPIACT>(p, stream);
         case CONV2_IDENT:
             if (!p.res) return hipErrorInvalidValue;
+            if (p.in_bf16) return launch_bf16<9, F_RES | F_INBF16>(p, stream);
             return launch_bf16<9, F_RES>(p, stream);
         case CONV2_SHORTCUT:
             if (!p.in2 || !p.w2_bf16 || !p.bias || p.Cin2 % 16 != 0 || (p.w_bf16_lo && !p.w2_bf16_lo))
                 return hipErrorInvalidValue;
+            if (p.in_bf16) return launch_bf16<9, F_PHASEB | F_BIAS | F_INBF16>(p, stream);
             return launch_bf16<9, F_PHASEB | F_BIAS>(p, stream);
         case TCONV_ACT:
             if (!p.pro_scale || !p.pro_shift || (p.up_h != 1 && p.up_h != 2)) return hipErrorInvalidValue;
@@ -412,9 +492,11 @@ hipError_t lass_launch_conv_bf16(ConvKind kind, const ConvArgs& p, hipStream_t s
             if (!p.pro_scale || !p.pro_shift || !p.epi_scale || !p.epi_shift || !p.pre_w || !p.pre_b || p.N != 32 ||
                 p.Cin != 32 || p.W % 32 != 0)
                 return hipErrorInvalidValue;
+            if (p.out_bf16) return launch_bf16_one<9, 1, 2, 32, F_PRO | F_EPIACT | F_PRECONV | F_OUTBF16>(p, stream);
             return launch_bf16_one<9, 1, 2, 32, F_PRO | F_EPIACT | F_PRECONV>(p, stream);
         case CONV2_IDENT_PRE:
             if (!p.res || !p.pre_w || !p.pre_b || p.N != 32 || p.W % 32 != 0) return hipErrorInvalidValue;
+            if (p.in_bf16) return launch_bf16_one<9, 1, 2, 32, F_RES | F_RESPRE | F_INBF16>(p, stream);
             return launch_bf16_one<9, 1, 2, 32, F_RES | F_RESPRE>(p, stream);
         default:
             return hipErrorInvalidValue;

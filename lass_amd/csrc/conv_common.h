@@ -16,6 +16,8 @@ constexpr int F_EPIACT = 16; // epilogue: leaky(v*scale[n] + shift[b][n])
 constexpr int F_TCONV = 32;  // n = (co, a, bb); scatter to (y*uh+a, x*uw+bb)
 constexpr int F_PRECONV = 64;   // input is the 1-channel x0; channel c = pre_w[c]*x0 + pre_b[c] is formed while staging
 constexpr int F_RESPRE = 128;   // with F_RES: the residual is pre_w[n]*x0 + pre_b[n] (never materialised)
+constexpr int F_OUTBF16 = 256;  // bf16 kernels: the output is the blocked bf16 intermediate [C/8][H][W][8] (+ lo plane)
+constexpr int F_INBF16 = 512;   // bf16 kernels: phase A reads that intermediate by LDS-DMA
 
 constexpr int NTHREADS = 256;
 
@@ -88,7 +90,27 @@ __device__ __forceinline__ void store_tile(const ConvArgs& p, f32x16 (&acc)[NCO]
                 if (EPI) v = leaky(v * lds_es[co * 32 + 4 * khalf + nl] + lds_eh[co * 32 + 4 * khalf + nl]);
                 val[px][r] = v;
             }
-            if (y < p.H) {
+            if ((FLAGS & F_OUTBF16) != 0) {
+                // blocked bf16 layout: unit (octet, y, x) = 16 B = 8 channels; this lane holds channels 4*khalf..+3 of the
+                // four octets g of its 32-cout tile -> one 8-byte store per octet (the khalf pair completes the unit)
+                if (y < p.H) {
+                    const size_t clip = (size_t)b * (p.N / 8) * HW;
+                    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const size_t unit = clip + (size_t)((n0 + co * 32) / 8 + g) * HW + (size_t)y * p.W + x;
+                        bf16x4 hi, lo;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            hi[i] = (__bf16)val[px][4 * g + i];
+                            lo[i] = (__bf16)(val[px][4 * g + i] - (float)hi[i]);
+                        }
+                        *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(p.out_bf16) + unit * 16 + khalf * 8) = hi;
+                        if (p.out_bf16_lo)
+                            *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(p.out_bf16_lo) + unit * 16 + khalf * 8) = lo;
+                    }
+                }
+            } else if (y < p.H) {
                 float* dst = p.out + (size_t)b * p.out_bs + pix;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) dst[(size_t)((r & 3) + 8 * (r >> 2)) * HW] = val[px][r];

@@ -44,6 +44,11 @@ struct ConvArgs {
     const void* w2_bf16 = nullptr;   // bf16 shortcut weights [Cin2/16][1][2][Nw][8]
     const void* w_bf16_lo = nullptr;   // split mode: bf16(w - float(bf16(w))), same layouts; non-null selects the 3-MFMA kernels
     const void* w2_bf16_lo = nullptr;
+    // bf16 modes: the block's intermediate (conv1 -> conv2) in the blocked bf16 layout [B][C/8][H][W][8], hi (+ lo) planes
+    void* out_bf16 = nullptr;
+    void* out_bf16_lo = nullptr;
+    const void* in_bf16 = nullptr;
+    const void* in_bf16_lo = nullptr;
     const float* pre_w = nullptr;  // pre_conv (1x1, 1 -> 32) weight / bias for the *_PRE kinds
     const float* pre_b = nullptr;
     float* pool_out = nullptr;  // fused avg-pool of the output: (B, N, H/pool_h, W/2) dense
