@@ -88,6 +88,7 @@ struct lass_ctx {
     bool wino = true;          // Winograd F(2x2,3x3) kernels for the 3x3 convs at W >= 32 (LASS_WINO=0: direct only)
     bool fuse_preconv = true;  // LASS_FUSE_PRECONV=0 materialises pre_conv's output with its own kernel
     bool fuse_pool = true;  // LASS_FUSE_POOL=0 selects the stand-alone pool kernel (A/B + parity of both paths)
+    bool fuse_mask = true;  // LASS_FUSE_MASK=0 keeps after_conv + mask as their own kernel behind decoder_block6
     bool profiling = false;
     std::vector<ProfEntry> prof;
     std::vector<hipEvent_t> ev_pool;
@@ -292,9 +293,19 @@ void prof_collect(lass_ctx* c) {
 // x: (B,cin,H,W) batch stride x_bs; out: batch stride out_bs (may be a channel slice of a concat buffer).
 // pool_out (optional): the block's avg-pooled output (B,cout,H/pool_h,W/2), produced by conv2's epilogue.
 // x0 (optional, encoder_block1 only): the block input is pre_conv(x0) and is formed on the fly - x is then ignored.
+// Output head fused into the last decoder block's conv2 (after_conv + complex ratio mask): inputs / outputs of the mask
+struct MaskHead {
+    const float* mag;
+    const float* cosv;
+    const float* sinv;
+    float* oreal;
+    float* oimag;
+    int T;
+};
+
 int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int B, int H, int W, const float* shift,
                  float* a2, float* out, long out_bs, hipStream_t st, float* pool_out = nullptr, int pool_h = 2,
-                 const float* x0 = nullptr) {
+                 const float* x0 = nullptr, const MaskHead* mh = nullptr) {
     const Site& s1 = c->sites[rb.s1];
     const Site& s2 = c->sites[rb.s2];
     const long HW = (long)H * W;
@@ -330,6 +341,12 @@ int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int
     q.out = out; q.out_bs = out_bs; q.B = B; q.H = H; q.W = W;
     q.pool_out = pool_out; q.pool_h = pool_h;
     q.w_wino = rb.u2; q.w2_wino = rb.usc;
+    if (mh) {  // the block output is consumed by the fused head and never written
+        q.out = nullptr;
+        q.mask_w = rawp(c, "base.after_conv.weight"); q.mask_b = rawp(c, "base.after_conv.bias");
+        q.mask_mag = mh->mag; q.mask_cos = mh->cosv; q.mask_sin = mh->sinv;
+        q.mask_re = mh->oreal; q.mask_im = mh->oimag; q.mask_T = mh->T;
+    }
     q.w_bf16 = rb.b2; q.w2_bf16 = rb.bsc16; q.w_bf16_lo = rb.b2l; q.w2_bf16_lo = rb.bscl;
     const bool bf2 = bf1;  // conv1 and conv2 of a block share shape and mode: both or neither
     if (bf2) { q.in_bf16 = a2_hi; q.in_bf16_lo = a2_lo; }
@@ -474,6 +491,7 @@ int lass_create(lass_ctx** out, int device_id) {
     c->device = device_id;
     if (const char* e = getenv("LASS_WINO")) c->wino = atoi(e) != 0;
     if (const char* e = getenv("LASS_FUSE_POOL")) c->fuse_pool = atoi(e) != 0;
+    if (const char* e = getenv("LASS_FUSE_MASK")) c->fuse_mask = atoi(e) != 0;
     if (const char* e = getenv("LASS_FUSE_PRECONV")) c->fuse_preconv = atoi(e) != 0;
     c->prof.resize(P_COUNT);
     for (int i = 0; i < P_COUNT; ++i) c->prof[i].name = kProfNames[i];
@@ -856,6 +874,7 @@ int lass_separate(lass_ctx* c, const float* mixture, const float* condition, flo
         }
     }
     // ---- decoder (resunet.py:563-568) -------------------------------------------------------------------------
+    bool fused_head = false;
     for (int d = 0; d < 6; ++d) {
         const int e = 5 - d;
         const int H = pl.eh[e], W = pl.ew[e];
@@ -864,12 +883,15 @@ int lass_separate(lass_ctx* c, const float* mixture, const float* condition, flo
         const ResBlock& rb = c->dec[d];
         r = run_upconv(c, d, x, B, h, w, shift, F(pl.cat[d]), 2 * rb.cout * HW, st);
         if (r) return r;
+        // decoder_block6 (32 channels at the full 512-bin resolution): after_conv + mask run in conv2's epilogue
+        const MaskHead head{F(pl.mag), F(pl.cosv), F(pl.sinv), F(pl.oreal), F(pl.oimag), T};
+        fused_head = d == 5 && c->fuse_mask && rb.cout == 32 && rb.cin != rb.cout && W == LASS_FCROP;
         r = run_resblock(c, rb, F(pl.cat[d]), 2 * rb.cout * HW, B, H, W, shift, F(pl.a2), F(pl.decout[d]),
-                         rb.cout * HW, st);
+                         rb.cout * HW, st, nullptr, 2, nullptr, fused_head ? &head : nullptr);
         if (r) return r;
         x = F(pl.decout[d]);
     }
-    {
+    if (!fused_head) {
         ProfScope ps(c, st, P_MASK);
         HIP_TRY(c, lass_launch_mask(x, rawp(c, "base.after_conv.weight"), rawp(c, "base.after_conv.bias"), F(pl.mag),
                                     F(pl.cosv), F(pl.sinv), B, T, Tp, F(pl.oreal), F(pl.oimag), st));

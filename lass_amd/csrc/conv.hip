@@ -338,9 +338,11 @@ __global__ __launch_bounds__(NTHREADS) void conv_kernel_sb(ConvArgs p) {
     using PB = Phase<1, 16, NCO, NPX, PW, false>;
     constexpr int LDS_ONE = HASB ? MaxI<PA::LDS_FLOATS, PB::LDS_FLOATS>::v : PA::LDS_FLOATS;
     constexpr int PH = PA::PH, WROWS = PA::WROWS, PHT = PA::PHT, NT = PA::NT;
-    constexpr int NTAB = (EPI ? 2 * NT : 0) + (BIAS ? NT : 0) + (RESPRE ? 2 * NT : 0);
+    constexpr bool MASK = (FLAGS & F_MASK) != 0;
+    constexpr int NTAB = (EPI ? 2 * NT : 0) + (BIAS ? NT : 0) + (RESPRE ? 2 * NT : 0) + (MASK ? 100 : 0);
 
     __shared__ __attribute__((aligned(16))) float lds[LDS_ONE + NTAB];
+    float* lds_mw = lds + LDS_ONE + NTAB - 100;  // MASK: after_conv weight [3][32] + bias [3]
     float* lds_es = lds + LDS_ONE;  // epilogue scale / shift for this block's NT output channels
     float* lds_eh = lds_es + NT;
     float* lds_bias = lds + LDS_ONE + (EPI ? 2 * NT : 0);
@@ -377,6 +379,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_kernel_sb(ConvArgs p) {
         lds_rw[tid] = p.pre_w[n0 + tid];
         lds_rb[tid] = p.pre_b[n0 + tid];
     }
+    if (MASK && tid < 99) lds_mw[tid] = tid < 96 ? p.mask_w[tid] : p.mask_b[tid - 96];
 
     PA pa;
     PB pb;
@@ -486,7 +489,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_kernel_sb(ConvArgs p) {
     if (FLAGS & F_TCONV)
         tconv_store<NCO, NPX, PW>(p, acc, b, n0, y0, x0, lane, wave);
     else
-        store_tile<NCO, NPX, PW, FLAGS, RES_PF>(p, acc, rtmp, lds_es, lds_eh, b, n0, y0, x0, lane, wave);
+        store_tile<NCO, NPX, PW, FLAGS, RES_PF>(p, acc, rtmp, lds_es, lds_eh, b, n0, y0, x0, lane, wave,
+                                                 MASK ? lds_mw : nullptr);
 #ifdef LASS_CONV_DIAG
     if (p.dbg && tid == 0) {
         const long long k_c3 = clock64(), k_r3 = wall_clock64();
@@ -611,7 +615,7 @@ static bool conv_args_ok(const ConvArgs& p, int taps, bool phaseb) {
     const int kc = taps == 9 ? 8 : 16;
     if (p.Cin <= 0 || p.Cin % (2 * kc) != 0) return false;  // even chunk count (run_db)
     if (phaseb && (p.Cin2 <= 0 || p.Cin2 % 32 != 0)) return false;
-    if (!p.in || !p.w || !p.out) return false;
+    if (!p.in || !p.w || (!p.out && !p.mask_re)) return false;
     return true;
 }
 
@@ -626,6 +630,12 @@ hipError_t lass_launch_conv(ConvKind kind, const ConvArgs& p, hipStream_t stream
             return launch_geom<9, F_RES>(p, stream);
         case CONV2_SHORTCUT:  // 3x3 over pre-activated input, + 1x1(in2) + bias
             if (!conv_args_ok(p, 9, true) || !p.in2 || !p.w2 || !p.bias) return hipErrorInvalidValue;
+            if (p.mask_re) {  // fused output head: decoder_block6 geometry only
+                if (p.N != 32 || p.W != LASS_FCROP || !p.mask_w || !p.mask_b || !p.mask_mag || !p.mask_cos || !p.mask_sin ||
+                    !p.mask_im || p.mask_T <= 0 || p.mask_T > p.H)
+                    return hipErrorInvalidValue;
+                return launch_one<9, 1, 2, 32, F_PHASEB | F_BIAS | F_MASK>(p, stream);
+            }
             return launch_geom<9, F_PHASEB | F_BIAS>(p, stream);
         case CONV1_ACT_PRE:  // encoder_block1.conv1 reading x0 directly (pre_conv fused into the staging)
             if (!conv_args_ok(p, 9, false) || !p.pro_scale || !p.pro_shift || !p.epi_scale || !p.epi_shift ||

@@ -259,13 +259,15 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
     constexpr int PA_LDS = INBF ? 2 * PA::IN_U4 + PA::W_U4 : PA::LDS_U4;  // INBF: two image buffers + one weight region
     constexpr int LDS_U4 = HASB ? MaxU<PA_LDS, PB::LDS_U4>::v : PA_LDS;
     constexpr int PH = PA::PH, WROWS = PA::WROWS, PHT = PA::PHT, NT = PA::NT;
-    constexpr int NTAB = (EPI ? 2 * NT : 0) + (BIAS ? NT : 0);
+    constexpr bool MASK = (FLAGS & F_MASK) != 0;
+    constexpr int NTAB = (EPI ? 2 * NT : 0) + (BIAS ? NT : 0) + (MASK ? 100 : 0);
 
     __shared__ uint4 lds4[LDS_U4 + (NTAB + 3) / 4];
     float* tabs = reinterpret_cast<float*>(lds4 + LDS_U4);
     float* lds_es = tabs;
     float* lds_eh = tabs + NT;
     float* lds_bias = tabs + (EPI ? 2 * NT : 0);
+    float* lds_mw = tabs + NTAB - 100;  // MASK: after_conv weight [3][32] + bias [3]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -293,6 +295,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
         lds_eh[tid] = p.epi_shift[(size_t)b * p.epi_shift_bs + n0 + tid];
     }
     if (BIAS && tid < NT) lds_bias[tid] = p.bias[n0 + tid];
+    if (MASK && tid < 99) lds_mw[tid] = tid < 96 ? p.mask_w[tid] : p.mask_b[tid - 96];
 
     PA pa;
     PB pb;
@@ -415,7 +418,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
     if (FLAGS & F_TCONV)
         tconv_store<NCO, NPX, PW>(p, acc, b, n0, y0, x0, lane, wave);
     else
-        store_tile<NCO, NPX, PW, FLAGS, RES_PF>(p, acc, rtmp, lds_es, lds_eh, b, n0, y0, x0, lane, wave);
+        store_tile<NCO, NPX, PW, FLAGS, RES_PF>(p, acc, rtmp, lds_es, lds_eh, b, n0, y0, x0, lane, wave,
+                                                 MASK ? lds_mw : nullptr);
 }
 
 // dst[chunk][tap][octet][Cout][8] (bf16, RNE) = src[co][ci = chunk*16 + octet*8 + j][tap]   (taps = 9 or 1)
@@ -468,7 +472,8 @@ bool lass_bf16_supported(const ConvArgs& p) {
 }
 
 hipError_t lass_launch_conv_bf16(ConvKind kind, const ConvArgs& p, hipStream_t stream) {
-    if (!lass_bf16_supported(p) || !p.w_bf16 || (!p.in && !p.in_bf16) || (!p.out && !p.out_bf16)) return hipErrorInvalidValue;
+    if (!lass_bf16_supported(p) || !p.w_bf16 || (!p.in && !p.in_bf16) || (!p.out && !p.out_bf16 && !p.mask_re))
+        return hipErrorInvalidValue;
     if ((p.in_bf16 || p.out_bf16) && (p.Cin % 8 != 0 || p.N % 8 != 0)) return hipErrorInvalidValue;
     if (p.w_bf16_lo && ((p.in_bf16 && !p.in_bf16_lo) || (p.out_bf16 && !p.out_bf16_lo))) return hipErrorInvalidValue;
     switch (kind) {
@@ -483,6 +488,12 @@ hipError_t lass_launch_conv_bf16(ConvKind kind, const ConvArgs& p, hipStream_t s
         case CONV2_SHORTCUT:
             if (!p.in2 || !p.w2_bf16 || !p.bias || p.Cin2 % 16 != 0 || (p.w_bf16_lo && !p.w2_bf16_lo))
                 return hipErrorInvalidValue;
+            if (p.mask_re) {  // fused output head: decoder_block6 geometry only
+                if (p.N != 32 || p.W != LASS_FCROP || !p.in_bf16 || !p.mask_w || !p.mask_b || !p.mask_mag || !p.mask_cos ||
+                    !p.mask_sin || !p.mask_im || p.mask_T <= 0 || p.mask_T > p.H)
+                    return hipErrorInvalidValue;
+                return launch_bf16_one<9, 1, 2, 32, F_PHASEB | F_BIAS | F_INBF16 | F_MASK>(p, stream);
+            }
             if (p.in_bf16) return launch_bf16<9, F_PHASEB | F_BIAS | F_INBF16>(p, stream);
             return launch_bf16<9, F_PHASEB | F_BIAS>(p, stream);
         case TCONV_ACT:

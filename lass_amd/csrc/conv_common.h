@@ -17,12 +17,34 @@ constexpr int F_TCONV = 32;  // n = (co, a, bb); scatter to (y*uh+a, x*uw+bb)
 constexpr int F_PRECONV = 64;   // input is the 1-channel x0; channel c = pre_w[c]*x0 + pre_b[c] is formed while staging
 constexpr int F_RESPRE = 128;   // with F_RES: the residual is pre_w[n]*x0 + pre_b[n] (never materialised)
 constexpr int F_OUTBF16 = 256;  // bf16 kernels: the output is the blocked bf16 intermediate [C/8][H][W][8] (+ lo plane)
+constexpr int F_MASK = 1024;    // epilogue = after_conv + complex ratio mask (see ConvArgs::mask_*); no tensor output
 constexpr int F_INBF16 = 512;   // bf16 kernels: phase A reads that intermediate by LDS-DMA
 
 constexpr int NTHREADS = 256;
 
 __device__ __forceinline__ float leaky(float v) { return fmaxf(v, 0.01f * v); }  // == v > 0 ? v : 0.01 v
 
+
+// The complex ratio mask of one time-frequency bin from its three after_conv logits (resunet.py:476-507; torchlibrosa
+// magphase clamps |M| at 1e-10); bin 512 is the zero padding of resunet.py:573, whose output is exactly 0.
+__device__ __forceinline__ void mask_pixel(const ConvArgs& p, int b, int t, int f, float l0, float l1, float l2) {
+    const size_t row = ((size_t)b * p.mask_T + t) * LASS_NBINS + f;
+    const float mask_mag = 1.f / (1.f + expf(-l0));
+    const float mr = tanhf(l1), mi = tanhf(l2);
+    const float mm = sqrtf(mr * mr + mi * mi);
+    const float den = fmaxf(mm, 1e-10f);
+    const float mc = mr / den, ms = mi / den;
+    const float ci = p.mask_cos[row], si = p.mask_sin[row];
+    const float oc = ci * mc - si * ms;
+    const float os = si * mc + ci * ms;
+    const float om = fmaxf(p.mask_mag[row] * mask_mag, 0.f);
+    p.mask_re[row] = om * oc;
+    p.mask_im[row] = om * os;
+    if (f == LASS_FCROP - 1) {
+        p.mask_re[row + 1] = 0.f;
+        p.mask_im[row + 1] = 0.f;
+    }
+}
 
 // Transposed-conv scatter: n = co_real*(uh*2) + a*2 + bb; registers (r, r+1), r even, are bb = 0/1 of one (co_real, a),
 // so each lane writes 8 contiguous bytes and a half-wave a contiguous 256-B run of the up-sampled row.
@@ -60,7 +82,8 @@ __device__ __forceinline__ void tconv_store(const ConvArgs& p, f32x16 (&acc)[NCO
 template <int NCO, int NPX, int PW, int FLAGS, bool HAVE_RTMP>
 __device__ __forceinline__ void store_tile(const ConvArgs& p, f32x16 (&acc)[NCO][NPX], const float (*rtmp)[16],
                                            const float* lds_es, const float* lds_eh, int b, int n0, int y0, int x0,
-                                           int lane, int wave) {
+                                           int lane, int wave, const float* lds_mw = nullptr) {
+    static_assert((FLAGS & F_MASK) == 0 || NCO == 1, "the fused output head needs all 32 channels in one wave");
     constexpr int PH = 32 / PW, WROWS = NPX * PH;
     constexpr bool EPI = (FLAGS & F_EPIACT) != 0;
     constexpr bool RES = (FLAGS & F_RES) != 0;
@@ -90,7 +113,19 @@ __device__ __forceinline__ void store_tile(const ConvArgs& p, f32x16 (&acc)[NCO]
                 if (EPI) v = leaky(v * lds_es[co * 32 + 4 * khalf + nl] + lds_eh[co * 32 + 4 * khalf + nl]);
                 val[px][r] = v;
             }
-            if ((FLAGS & F_OUTBF16) != 0) {
+            if ((FLAGS & F_MASK) != 0) {
+                // NCO == 1, N == 32: this lane and its khalf partner hold all 32 channels of the pixel
+                float l[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s += lds_mw[q * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf] * val[px][r];
+                    s += __shfl_xor(s, 32, 64);
+                    l[q] = s + lds_mw[96 + q];
+                }
+                if (khalf == 0 && y < p.mask_T) mask_pixel(p, b, y, x, l[0], l[1], l[2]);
+            } else if ((FLAGS & F_OUTBF16) != 0) {
                 // blocked bf16 layout: unit (octet, y, x) = 16 B = 8 channels; this lane holds channels 4*khalf..+3 of the
                 // four octets g of its 32-cout tile -> one 8-byte store per octet (the khalf pair completes the unit)
                 if (y < p.H) {

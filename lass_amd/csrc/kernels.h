@@ -51,6 +51,16 @@ struct ConvArgs {
     const void* in_bf16_lo = nullptr;
     const float* pre_w = nullptr;  // pre_conv (1x1, 1 -> 32) weight / bias for the *_PRE kinds
     const float* pre_b = nullptr;
+    // fused output head (decoder_block6.conv2 only, N == 32, W == 512): after_conv (1x1, 32 -> 3, + bias) and the complex
+    // ratio mask (resunet.py:570-574,436-519) in the epilogue; the block's own output is then not written at all
+    const float* mask_w = nullptr;    // after_conv.weight [3][32]
+    const float* mask_b = nullptr;    // after_conv.bias [3]
+    const float* mask_mag = nullptr;  // (B, mask_T, 513) mixture magnitude / cos / sin
+    const float* mask_cos = nullptr;
+    const float* mask_sin = nullptr;
+    float* mask_re = nullptr;         // (B, mask_T, 513) separated spectrum
+    float* mask_im = nullptr;
+    int mask_T = 0;                   // frames (rows y >= mask_T are the T padding: dropped)
     float* pool_out = nullptr;  // fused avg-pool of the output: (B, N, H/pool_h, W/2) dense
     int pool_h = 2;              // vertical pool factor (1 or 2); horizontal is 2
     long long* dbg = nullptr;  // diagnostic builds (-DLASS_CONV_DIAG) only: 8 int64 per block

@@ -26,6 +26,7 @@
 namespace {
 
 constexpr int F_PRO = 1, F_PHASEB = 2, F_BIAS = 4, F_RES = 8, F_EPIACT = 16;
+constexpr int F_MASK = 1024;    // epilogue = after_conv + complex ratio mask (ConvArgs::mask_*); the block output is not written
 constexpr int F_PRECONV = 64;   // input is the 1-channel x0; channel c = pre_w[c]*x0 + pre_b[c] is formed while staging
 constexpr int F_RESPRE = 128;   // with F_RES: the residual is pre_w[n]*x0 + pre_b[n]
 constexpr int NTHREADS = 256;
@@ -34,6 +35,27 @@ constexpr int KCB = 32;  // shortcut phase: 32 channels x 4 xi per chunk (the sa
 constexpr int PWT = 16;  // Winograd tiles per row pair (32 output columns)
 
 __device__ __forceinline__ float leaky(float v) { return fmaxf(v, 0.01f * v); }
+
+// The complex ratio mask of one time-frequency bin from its three after_conv logits (resunet.py:476-507; torchlibrosa
+// magphase clamps |M| at 1e-10); bin 512 is the zero padding of resunet.py:573, whose output is exactly 0.
+__device__ __forceinline__ void mask_pixel(const ConvArgs& p, int b, int t, int f, float l0, float l1, float l2) {
+    const size_t row = ((size_t)b * p.mask_T + t) * LASS_NBINS + f;
+    const float mask_mag = 1.f / (1.f + expf(-l0));
+    const float mr = tanhf(l1), mi = tanhf(l2);
+    const float mm = sqrtf(mr * mr + mi * mi);
+    const float den = fmaxf(mm, 1e-10f);
+    const float mc = mr / den, ms = mi / den;
+    const float ci = p.mask_cos[row], si = p.mask_sin[row];
+    const float oc = ci * mc - si * ms;
+    const float os = si * mc + ci * ms;
+    const float om = fmaxf(p.mask_mag[row] * mask_mag, 0.f);
+    p.mask_re[row] = om * oc;
+    p.mask_im[row] = om * os;
+    if (f == LASS_FCROP - 1) {
+        p.mask_re[row + 1] = 0.f;
+        p.mask_im[row + 1] = 0.f;
+    }
+}
 
 // Halo-tile staging: [KC][IR][IP] raw (activated) input, walked in channel pairs (see conv.hip Phase).
 template <int IR, int IP, int HALO, int KCH, bool PRO, bool PRE = false>
@@ -182,7 +204,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
     constexpr int V_F = 16 * KC * VP;
     constexpr int U_F = 16 * KC * NT;
     constexpr int MAXC = 768;  // largest Cin of a 3x3 conv in the network (decoder_block1/2.conv1)
-    constexpr int NTAB = (EPI ? 2 * NT : 0) + (BIAS ? NT : 0) + (PRO ? 2 * MAXC : 0) + ((PRE || RESPRE) ? 64 : 0);
+    constexpr bool MASK = (FLAGS & F_MASK) != 0;
+    static_assert(!MASK || WCO == 1, "the fused output head needs all 32 channels in one wave");
+    constexpr int NTAB = (EPI ? 2 * NT : 0) + (BIAS ? NT : 0) + (PRO ? 2 * MAXC : 0) + ((PRE || RESPRE) ? 64 : 0) + (MASK ? 100 : 0);
     static_assert(RAW_F % 4 == 0 && V_F % 4 == 0, "16-B alignment of the LDS regions");
 
     __shared__ __attribute__((aligned(16))) float lds[RAW_F + V_F + U_F + NTAB];
@@ -196,6 +220,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
     float* lds_sh = lds_sc + MAXC;
     float* lds_pw = lu + U_F + (EPI ? 2 * NT : 0) + (BIAS ? NT : 0) + (PRO ? 2 * MAXC : 0);  // pre_conv weight / bias (32+32)
     float* lds_pb = lds_pw + 32;
+    float* lds_mw = lds + RAW_F + V_F + U_F + NTAB - 100;  // MASK: after_conv weight [3][32] + bias [3]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // uniform to the compiler too
@@ -224,6 +249,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
         lds_pw[tid] = p.pre_w[tid];
         lds_pb[tid] = p.pre_b[tid];
     }
+    if (MASK && tid < 99) lds_mw[tid] = tid < 96 ? p.mask_w[tid] : p.mask_b[tid - 96];
 
 #ifdef LASS_CONV_DIAG
     const long long k_c0 = clock64(), k_r0 = wall_clock64();
@@ -400,6 +426,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
     // ---- output transform Y = A^T M A and epilogue -----------------------------------------------------------------
     const int wty = wwt, wtx = l15;  // this lane's tile: row pair wwt of the block, column pair l15
     const int oy = y0 + 2 * wty, ox = x0 + 2 * wtx;
+    float ml[3][2][2] = {};  // MASK: this lane's partial after_conv logits of its 2x2 pixels (8 of the 32 channels)
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
 #pragma unroll
@@ -439,6 +466,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
                 y[0][0] = leaky(y[0][0] * es + eh); y[0][1] = leaky(y[0][1] * es + eh);
                 y[1][0] = leaky(y[1][0] * es + eh); y[1][1] = leaky(y[1][1] * es + eh);
             }
+            if (MASK) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float wk = lds_mw[k * 32 + nl];
+                    ml[k][0][0] += wk * y[0][0]; ml[k][0][1] += wk * y[0][1];
+                    ml[k][1][0] += wk * y[1][0]; ml[k][1][1] += wk * y[1][1];
+                }
+                continue;
+            }
             float* dst = p.out + (size_t)b * p.out_bs + pix;
             if (oy < p.H) *reinterpret_cast<float2*>(dst) = make_float2(y[0][0], y[0][1]);
             if (oy + 1 < p.H) *reinterpret_cast<float2*>(dst + p.W) = make_float2(y[1][0], y[1][1]);
@@ -458,6 +494,24 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
                 }
             }
         }
+    }
+    if (MASK) {
+        // the four lanes l15 + 16*kq hold the tile's 32 channels between them: butterfly over kq, then lane kq finishes
+        // pixel (kq >> 1, kq & 1) of the 2x2 tile
+        float l[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float v = ml[k][i][j];
+                    v += __shfl_xor(v, 16, 64);
+                    v += __shfl_xor(v, 32, 64);
+                    if (kq == i * 2 + j) l[k] = v + lds_mw[96 + k];
+                }
+        const int t = oy + (kq >> 1), f = ox + (kq & 1);
+        if (t < p.mask_T) mask_pixel(p, b, t, f, l[0], l[1], l[2]);
     }
 #ifdef LASS_CONV_DIAG
     if (p.dbg && tid == 0) {
@@ -517,10 +571,15 @@ hipError_t launch_wino(const ConvArgs& p0, hipStream_t stream) {
     }
     p.dbg = dbuf;
 #endif
-    if (wide)
-        hipLaunchKernelGGL((wino_kernel<2, 2, FLAGS>), grid, dim3(NTHREADS), 0, stream, p);
-    else
+    if constexpr ((FLAGS & F_MASK) != 0) {
+        if (wide) return hipErrorInvalidValue;  // N == 32 only (host-checked)
         hipLaunchKernelGGL((wino_kernel<1, 4, FLAGS>), grid, dim3(NTHREADS), 0, stream, p);
+    } else {
+        if (wide)
+            hipLaunchKernelGGL((wino_kernel<2, 2, FLAGS>), grid, dim3(NTHREADS), 0, stream, p);
+        else
+            hipLaunchKernelGGL((wino_kernel<1, 4, FLAGS>), grid, dim3(NTHREADS), 0, stream, p);
+    }
 #ifdef LASS_CONV_DIAG
     {
         std::vector<long long> h(nblk * 8);
@@ -548,7 +607,7 @@ bool lass_wino_supported(const ConvArgs& p) {
 }
 
 hipError_t lass_launch_wino(ConvKind kind, const ConvArgs& p, hipStream_t stream) {
-    if (!lass_wino_supported(p) || !p.w_wino || !p.in || !p.out) return hipErrorInvalidValue;
+    if (!lass_wino_supported(p) || !p.w_wino || !p.in || (!p.out && !p.mask_re)) return hipErrorInvalidValue;
     switch (kind) {
         case CONV1_ACT:
             if (!p.pro_scale || !p.pro_shift || !p.epi_scale || !p.epi_shift) return hipErrorInvalidValue;
@@ -558,6 +617,12 @@ hipError_t lass_launch_wino(ConvKind kind, const ConvArgs& p, hipStream_t stream
             return launch_wino<F_RES>(p, stream);
         case CONV2_SHORTCUT:
             if (!p.in2 || !p.w2_wino || !p.bias || p.Cin2 % KCB != 0) return hipErrorInvalidValue;
+            if (p.mask_re) {  // fused output head: decoder_block6 geometry only
+                if (p.N != 32 || p.W != LASS_FCROP || !p.mask_w || !p.mask_b || !p.mask_mag || !p.mask_cos || !p.mask_sin ||
+                    !p.mask_im || p.mask_T <= 0 || p.mask_T > p.H)
+                    return hipErrorInvalidValue;
+                return launch_wino<F_PHASEB | F_BIAS | F_MASK>(p, stream);
+            }
             return launch_wino<F_PHASEB | F_BIAS>(p, stream);
         case CONV1_ACT_PRE:
             if (!p.pro_scale || !p.pro_shift || !p.epi_scale || !p.epi_shift || !p.pre_w || !p.pre_b || p.N != 32 ||

@@ -360,6 +360,31 @@ def test_mix_at_snr_vs_reference_formula(eng):
         assert float(np.max(np.abs(got_src[b] - exp_src[b]))) < 2e-6 * max(scale, 1.0)
 
 
+def test_fusion_switches_agree(synthetic_sd, monkeypatch):
+    """The fused paths (output head in decoder_block6's epilogue, avg-pool and pre_conv fusions, Winograd) against the
+    stand-alone kernels they replace: same waveform to f32 summation-order noise.  The switches are read at lass_create."""
+    from lass_amd.resunet import ResUNet30
+    _, mix = synthetic.make_mixtures(2, 24000)
+    inp = {"mixture": torch.from_numpy(mix)[:, None, :].to(DEV), "condition": torch.from_numpy(synthetic.make_condition(2)).to(DEV)}
+
+    def run(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        m = ResUNet30(1, 1, 512)
+        m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synthetic_sd.items()})
+        out = m.to(DEV).eval()(inp)["waveform"].cpu()
+        for k in env:
+            monkeypatch.delenv(k)
+        return out
+
+    ref = run({})
+    scale = float(ref.pow(2).mean().sqrt())
+    for env in ({"LASS_FUSE_MASK": "0"}, {"LASS_FUSE_POOL": "0", "LASS_FUSE_PRECONV": "0"}, {"LASS_WINO": "0"},
+                {"LASS_WINO": "0", "LASS_FUSE_MASK": "0"}):
+        got = run(env)
+        assert float((got - ref).pow(2).mean().sqrt()) < 2e-5 * scale, env
+
+
 # ---- BASELINE configs[2]: bf16-MFMA convolutions (reduced precision by design; its own tolerances) --------------------
 def test_bf16_mode_convblock_and_waveform(synthetic_sd, oracle_sd):
     """Operands of the 3x3 convs are rounded to bf16 (8-bit mantissa, ~4e-3 relative each): per-block outputs must
