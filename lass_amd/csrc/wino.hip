@@ -18,6 +18,7 @@
 // at the four xi in {1,2}x{1,2} only, and its B^T d B there needs just the 2x2 centre of the patch.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <type_traits>
 #include <vector>
 #include "kernels.h"
@@ -32,7 +33,6 @@ constexpr int F_RESPRE = 128;   // with F_RES: the residual is pre_w[n]*x0 + pre
 constexpr int NTHREADS = 256;
 constexpr int KC = 8;
 constexpr int KCB = 32;  // shortcut phase: 32 channels x 4 xi per chunk (the same 128 LDS rows and 64 MFMAs as a 3x3 chunk)
-constexpr int PWT = 16;  // Winograd tiles per row pair (32 output columns)
 
 __device__ __forceinline__ float leaky(float v) { return fmaxf(v, 0.01f * v); }
 
@@ -181,8 +181,10 @@ struct UDma {
     }
 };
 
-// WCO x WWT waves (product 4): block = 32*WCO couts x 16*WWT Winograd tiles = (2*WWT output rows) x 32 output cols.
-template <int WCO, int WWT, int FLAGS>
+// WCO x WWT waves (product 4): block = 32*WCO couts x 16*WWT Winograd tiles, PWT of them per row pair: the block covers
+// 2*PWT output columns x 2*(16*WWT/PWT) output rows (PWT = 16: 32 columns; 8 / 4: the 16- and 8-bin layers at the bottom
+// of the U-Net, whose 32-tile blocks are folded into more rows).
+template <int WCO, int WWT, int FLAGS, int PWT = 16>
 __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
     static_assert(WCO * WWT == 4, "4 waves");
     constexpr bool PRO = (FLAGS & F_PRO) != 0;
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
     constexpr bool RESPRE = (FLAGS & F_RESPRE) != 0;
     constexpr int NT = 32 * WCO;
     constexpr int NWT = 16 * WWT;
-    constexpr int OR_ = 2 * WWT, OC = 2 * PWT;  // output rows / cols of the block
+    constexpr int OR_ = 2 * (NWT / PWT), OC = 2 * PWT;  // output rows / cols of the block
     constexpr int IR = OR_ + 2, IP = OC + 2;
     constexpr int VP = NWT + 16;  // V row pitch (floats): spreads the 4 k-rows of a fragment read over the banks
     using RA = RawStage<IR, IP, 1, KC, PRO, PRE>;
@@ -424,7 +426,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
     }
 
     // ---- output transform Y = A^T M A and epilogue -----------------------------------------------------------------
-    const int wty = wwt, wtx = l15;  // this lane's tile: row pair wwt of the block, column pair l15
+    const int wty = (wwt * 16 + l15) / PWT, wtx = (wwt * 16 + l15) % PWT;  // this lane's tile within the block
     const int oy = y0 + 2 * wty, ox = x0 + 2 * wtx;
     float ml[3][2][2] = {};  // MASK: this lane's partial after_conv logits of its 2x2 pixels (8 of the 32 channels)
 #pragma unroll
@@ -559,6 +561,20 @@ template <int FLAGS>
 hipError_t launch_wino(const ConvArgs& p0, hipStream_t stream) {
     ConvArgs p = p0;
     const bool wide = p.N % 64 == 0;
+    if (p.W < 32) {  // 16- / 8-bin layers: 64-cout blocks of 8 x 16 or 16 x 8 output pixels
+        if constexpr ((FLAGS & (F_MASK | F_PRECONV | F_RESPRE)) != 0) {
+            return hipErrorInvalidValue;
+        } else {
+            if (!wide || (p.W != 16 && p.W != 8)) return hipErrorInvalidValue;
+            if (p.W == 16)
+                hipLaunchKernelGGL((wino_kernel<2, 2, FLAGS, 8>), dim3((p.H + 7) / 8, p.N / 64, p.B), dim3(NTHREADS), 0,
+                                   stream, p);
+            else
+                hipLaunchKernelGGL((wino_kernel<2, 2, FLAGS, 4>), dim3((p.H + 15) / 16, p.N / 64, p.B), dim3(NTHREADS), 0,
+                                   stream, p);
+            return hipGetLastError();
+        }
+    }
     dim3 grid = wide ? dim3((p.W / 32) * ((p.H + 3) / 4), p.N / 64, p.B) : dim3((p.W / 32) * ((p.H + 7) / 8), p.N / 32, p.B);
 #ifdef LASS_CONV_DIAG
     static long long* dbuf = nullptr;
@@ -603,7 +619,9 @@ hipError_t launch_wino(const ConvArgs& p0, hipStream_t stream) {
 }  // namespace
 
 bool lass_wino_supported(const ConvArgs& p) {
-    return p.W >= 32 && (p.W % 32) == 0 && (p.H % 2) == 0 && p.Cin % (2 * KC) == 0 && p.N % 32 == 0 && (p.Nw % 4) == 0;
+    static const bool small_ok = [] { const char* e = getenv("LASS_WINO_SMALL"); return !e || atoi(e) != 0; }();
+    const bool w_ok = (p.W >= 32 && (p.W % 32) == 0) || (small_ok && (p.W == 16 || p.W == 8) && p.N % 64 == 0);
+    return w_ok && (p.H % 2) == 0 && p.Cin % (2 * KC) == 0 && p.N % 32 == 0 && (p.Nw % 4) == 0;
 }
 
 hipError_t lass_launch_wino(ConvKind kind, const ConvArgs& p, hipStream_t stream) {
