@@ -156,15 +156,15 @@ def main():
         per_step_ms = ms / args.steps
         achieved = conv_flops / (per_step_ms * 1e-3) / 1e12 if per_step_ms > 0 else 0.0
         traffic, traffic_meta = pmc_traffic() if (B, L) == (16, 160000) else (None, None)
-        # With the Winograd kernels (default) the 3x3 convs at W >= 32 execute 4 instead of 9 multiplies per output and
+        # With the Winograd kernels (default) the 3x3 convs (even H) execute 4 instead of 9 multiplies per output and
         # (cin, cout): `achieved` stays the ALGORITHMIC (direct-convolution) rate and may exceed the MFMA peak; the
         # rate the matrix pipe really sustains is `executed_tflops`.
         wino = os.environ.get("LASS_WINO", "1") != "0"
         exec_flops = 0.0
         for r in rows:
             if r["kind"] == "3x3":
-                exec_flops += 2.0 * B * r["macs"] * ((4.0 / 9.0) if (wino and r["w"] >= 32 and r["h"] % 2 == 0) else 1.0)
-            elif r["name"].endswith(".shortcut"):
+                exec_flops += 2.0 * B * r["macs"] * ((4.0 / 9.0) if (wino and r["h"] % 2 == 0) else 1.0)
+            elif r["name"].endswith(".shortcut"):  # transform-domain 1x1: 4 of 16 xi per 2x2 tile = direct-1x1 count
                 exec_flops += 2.0 * B * r["macs"]
         executed = exec_flops / (per_step_ms * 1e-3) / 1e12 if per_step_ms > 0 else 0.0
         peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
