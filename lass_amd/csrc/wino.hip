@@ -184,7 +184,10 @@ struct UDma {
 // WCO x WWT waves (product 4): block = 32*WCO couts x 16*WWT Winograd tiles, PWT of them per row pair: the block covers
 // 2*PWT output columns x 2*(16*WWT/PWT) output rows (PWT = 16: 32 columns; 8 / 4: the 16- and 8-bin layers at the bottom
 // of the U-Net, whose 32-tile blocks are folded into more rows).
-template <int WCO, int WWT, int FLAGS, int PWT = 16>
+// PATCH: every thread loads its 4x4 input patch(es) straight from global (two 8-byte loads per patch row, two chunks
+// ahead), applies the prologue and the zero padding and transforms in registers - no raw LDS tile, two barriers per chunk
+// instead of three (the barrier -> LDS -> transform -> LDS -> barrier latency chain is what the chunk time is made of).
+template <int WCO, int WWT, int FLAGS, int PWT = 16, bool PATCH = false>
 __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
     static_assert(WCO * WWT == 4, "4 waves");
     constexpr bool PRO = (FLAGS & F_PRO) != 0;
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
     using RA = RawStage<IR, IP, 1, KC, PRO, PRE>;
     using UA = UDma<16, NT>;
     using UB = UDma<4, NT, KCB>;
-    constexpr int RAW_F = KC * IR * IP;
+    constexpr int RAW_F = PATCH ? 0 : KC * IR * IP;
     constexpr int V_F = 16 * KC * VP;
     constexpr int U_F = 16 * KC * NT;
     constexpr int MAXC = 768;  // largest Cin of a 3x3 conv in the network (decoder_block1/2.conv1)
@@ -276,7 +279,107 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
     //             transform raw->V | wait U(ch) (counted vmcnt: the raw(ch+2) loads stay in flight) | barrier |
     //             MFMAs
     const unsigned lu_addr = (unsigned)(size_t)(__attribute__((address_space(3))) float*)lu;
-    {
+    if constexpr (PATCH) {
+        constexpr int CSTEP = NTHREADS / NWT;  // a thread owns ONE tile position and channels cb + i*CSTEP of the chunk
+        constexpr int NIT = KC / CSTEP;        // patches per thread and chunk
+        typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+        const int wt = tid % NWT, cb = tid / NWT;
+        const int pty = wt / PWT, ptx = wt % PWT;
+        const int gy0 = y0 + 2 * pty - 1, gx0 = x0 + 2 * ptx - 1;
+        const bool left = gx0 < 0, right = gx0 + 3 >= p.W;
+        unsigned voa[4], vob[4], rowok = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int gy = gy0 + i;
+            const int row = min(max(gy, 0), p.H - 1) * p.W + (PRE ? 0 : cb * HW);
+            voa[i] = 4u * (unsigned)(row + (left ? 0 : gx0));            // pair (gx0, gx0+1); at the left edge (0, 1)
+            vob[i] = 4u * (unsigned)(row + (right ? p.W - 2 : gx0 + 2));  // pair (gx0+2, gx0+3); right edge (W-2, W-1)
+            rowok |= (gy >= 0 && gy < p.H ? 1u : 0u) << i;
+        }
+        const __amdgpu_buffer_rsrc_t in_rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_b), 0, (PRE ? 1 : p.Cin) * HW * 4, 0x00020000);
+        f2u ps[PRE ? 1 : 2][NIT][8];
+        auto pload = [&](int ch, auto buf) {
+            constexpr int BUF = decltype(buf)::value;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const unsigned soff = PRE ? 0u : (unsigned)((ch * KC + it * CSTEP) * HW) * 4u;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    ps[BUF][it][2 * i] = __builtin_bit_cast(f2u, __builtin_amdgcn_raw_buffer_load_b64(in_rsrc, (int)voa[i], (int)soff, 0));
+                    ps[BUF][it][2 * i + 1] = __builtin_bit_cast(f2u, __builtin_amdgcn_raw_buffer_load_b64(in_rsrc, (int)vob[i], (int)soff, 0));
+                }
+            }
+        };
+        auto pprocess = [&](int ch, auto buf) {
+            constexpr int BUF = decltype(buf)::value;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int c = ch * KC + cb + it * CSTEP;
+                const float s1 = PRO ? lds_sc[c] : 0.f, s2 = PRO ? lds_sh[c] : 0.f;
+                const float pw = PRE ? lds_pw[c] : 0.f, pb = PRE ? lds_pb[c] : 0.f;
+                float d[4][4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const f2u a = ps[PRE ? 0 : BUF][PRE ? 0 : it][2 * i], bq = ps[PRE ? 0 : BUF][PRE ? 0 : it][2 * i + 1];
+                    float v0 = a.x, v1 = left ? a.x : a.y, v2 = right ? bq.y : bq.x, v3 = bq.y;
+                    if (PRE) { v0 = v0 * pw + pb; v1 = v1 * pw + pb; v2 = v2 * pw + pb; v3 = v3 * pw + pb; }
+                    if (PRO) {
+                        v0 = leaky(v0 * s1 + s2); v1 = leaky(v1 * s1 + s2);
+                        v2 = leaky(v2 * s1 + s2); v3 = leaky(v3 * s1 + s2);
+                    }
+                    const bool rok = ((rowok >> i) & 1u) != 0;  // zero padding comes AFTER the activation
+                    d[i][0] = (rok && !left) ? v0 : 0.f;
+                    d[i][1] = rok ? v1 : 0.f;
+                    d[i][2] = rok ? v2 : 0.f;
+                    d[i][3] = (rok && !right) ? v3 : 0.f;
+                }
+                float tt[4][4];
+#pragma unroll
+                for (int jx = 0; jx < 4; ++jx) {
+                    tt[0][jx] = d[0][jx] - d[2][jx];
+                    tt[1][jx] = d[1][jx] + d[2][jx];
+                    tt[2][jx] = d[2][jx] - d[1][jx];
+                    tt[3][jx] = d[1][jx] - d[3][jx];
+                }
+                float* dst = lv + (cb + it * CSTEP) * VP + wt;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    dst[(4 * i + 0) * (KC * VP)] = tt[i][0] - tt[i][2];
+                    dst[(4 * i + 1) * (KC * VP)] = tt[i][1] + tt[i][2];
+                    dst[(4 * i + 2) * (KC * VP)] = tt[i][2] - tt[i][1];
+                    dst[(4 * i + 3) * (KC * VP)] = tt[i][1] - tt[i][3];
+                }
+            }
+        };
+        const int nch = p.Cin / KC;  // even (host-checked)
+        pload(0, std::integral_constant<int, 0>{});
+        if (!PRE) pload(1, std::integral_constant<int, 1>{});
+        const unsigned ulane = UA::lane_base(p.Nw, lane);
+        const v4i32 uw_n0 = make_rsrc_words(p.w_wino + n0, (unsigned)(16 * p.Cin * p.Nw - n0) * 4u);
+        lds_barrier();  // prologue tables visible
+        auto chunk = [&](int ch, auto buf) {
+            constexpr int BUF = decltype(buf)::value;
+            lds_barrier();  // previous chunk's MFMAs have finished reading V / U
+            pprocess(ch, buf);
+            __builtin_amdgcn_sched_barrier(0);
+            UA::issue(uw_n0, ulane, p.Cin, p.Nw, ch * KC, lu_addr, wave);
+            __builtin_amdgcn_sched_barrier(0);
+            const bool pf = !PRE && ch + 2 < nch;
+            if (pf) pload(ch + 2, buf);
+            __builtin_amdgcn_sched_barrier(0);
+            if (pf)
+                wait_vmcnt<NIT * 8>();  // this wave's U(ch) rows have landed; the patches of chunk ch+2 stay in flight
+            else
+                wait_vmcnt<0>();
+            lds_barrier();  // V visible, every wave's U rows landed
+            gemm_steps<16 * (KC / 4), NT, VP>(afrag0, afrag1, bfrag, acc, [](int s) { return s / (KC / 4); });
+        };
+        for (int ch = 0; ch < nch; ch += 2) {
+            chunk(ch, std::integral_constant<int, 0>{});
+            chunk(ch + 1, std::integral_constant<int, 1>{});
+        }
+    } else {
         RA ra;
         ra.init(tid, y0, x0, p.H, p.W);
         const int nch = p.Cin / KC;  // even (host-checked)
@@ -557,8 +660,8 @@ __global__ __launch_bounds__(256) void wino_shortcut_weights_kernel(const float*
     for (int q = 0; q < 4; ++q) U[((size_t)q * Cin + ci) * Cout + co] = sgn[q] * v;
 }
 
-template <int FLAGS>
-hipError_t launch_wino(const ConvArgs& p0, hipStream_t stream) {
+template <int FLAGS, bool PATCH>
+hipError_t launch_wino_v(const ConvArgs& p0, hipStream_t stream) {
     ConvArgs p = p0;
     const bool wide = p.N % 64 == 0;
     if (p.W < 32) {  // 16- / 8-bin layers: 64-cout blocks of 8 x 16 or 16 x 8 output pixels
@@ -567,10 +670,10 @@ hipError_t launch_wino(const ConvArgs& p0, hipStream_t stream) {
         } else {
             if (!wide || (p.W != 16 && p.W != 8)) return hipErrorInvalidValue;
             if (p.W == 16)
-                hipLaunchKernelGGL((wino_kernel<2, 2, FLAGS, 8>), dim3((p.H + 7) / 8, p.N / 64, p.B), dim3(NTHREADS), 0,
+                hipLaunchKernelGGL((wino_kernel<2, 2, FLAGS, 8, PATCH>), dim3((p.H + 7) / 8, p.N / 64, p.B), dim3(NTHREADS), 0,
                                    stream, p);
             else
-                hipLaunchKernelGGL((wino_kernel<2, 2, FLAGS, 4>), dim3((p.H + 15) / 16, p.N / 64, p.B), dim3(NTHREADS), 0,
+                hipLaunchKernelGGL((wino_kernel<2, 2, FLAGS, 4, PATCH>), dim3((p.H + 15) / 16, p.N / 64, p.B), dim3(NTHREADS), 0,
                                    stream, p);
             return hipGetLastError();
         }
@@ -589,12 +692,12 @@ hipError_t launch_wino(const ConvArgs& p0, hipStream_t stream) {
 #endif
     if constexpr ((FLAGS & F_MASK) != 0) {
         if (wide) return hipErrorInvalidValue;  // N == 32 only (host-checked)
-        hipLaunchKernelGGL((wino_kernel<1, 4, FLAGS>), grid, dim3(NTHREADS), 0, stream, p);
+        hipLaunchKernelGGL((wino_kernel<1, 4, FLAGS, 16, PATCH>), grid, dim3(NTHREADS), 0, stream, p);
     } else {
         if (wide)
-            hipLaunchKernelGGL((wino_kernel<2, 2, FLAGS>), grid, dim3(NTHREADS), 0, stream, p);
+            hipLaunchKernelGGL((wino_kernel<2, 2, FLAGS, 16, PATCH>), grid, dim3(NTHREADS), 0, stream, p);
         else
-            hipLaunchKernelGGL((wino_kernel<1, 4, FLAGS>), grid, dim3(NTHREADS), 0, stream, p);
+            hipLaunchKernelGGL((wino_kernel<1, 4, FLAGS, 16, PATCH>), grid, dim3(NTHREADS), 0, stream, p);
     }
 #ifdef LASS_CONV_DIAG
     {
@@ -614,6 +717,16 @@ hipError_t launch_wino(const ConvArgs& p0, hipStream_t stream) {
     }
 #endif
     return hipGetLastError();
+}
+
+// The patch-staging schedule wins on the 16- / 8-bin layers (-9...-13 %: few, short tiles) and loses 3-7 % on the large
+// ones (its 16 instead of ~9 prologue evaluations per thread and chunk are VALU work next to f32 MFMAs), so it is the
+// default below W = 32 only; LASS_WINO_PATCH=0/1 forces it off / on everywhere (A/B switch).
+template <int FLAGS>
+hipError_t launch_wino(const ConvArgs& p, hipStream_t stream) {
+    static const int force = [] { const char* e = getenv("LASS_WINO_PATCH"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
+    const bool patch = force >= 0 ? force == 1 : p.W < 32;
+    return patch ? launch_wino_v<FLAGS, true>(p, stream) : launch_wino_v<FLAGS, false>(p, stream);
 }
 
 }  // namespace
