@@ -258,6 +258,46 @@ def test_silence_and_edge_lengths(model, oracle_sd):
         assert _rms(out.cpu() - ref) < 2e-6
 
 
+def test_c_abi_error_paths(eng, synthetic_sd):
+    """Every misuse returns a negative code with a message (no crash, no silent fallback): include/lass_hip.h contract."""
+    from ctypes import byref, c_size_t, c_void_p
+    from lass_amd import _lib
+    from lass_amd.engine import Engine
+    lib = eng.lib
+    mix = torch.zeros(2, 4000, device=DEV)
+    cond = torch.zeros(2, 512, device=DEV)
+    out = torch.empty_like(mix)
+    ws = torch.empty(eng.workspace_bytes(2, 4000), dtype=torch.uint8, device=DEV)
+    st = c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: c_void_p(t.data_ptr())  # noqa: E731
+    # workspace too small / null pointers / clip shorter than the reflect padding
+    assert lib.lass_separate(eng.ctx, P(mix), P(cond), P(out), 2, 4000, P(ws), 1024, st) < 0
+    assert b"workspace" in lib.lass_last_error(eng.ctx)
+    assert lib.lass_separate(eng.ctx, c_void_p(0), P(cond), P(out), 2, 4000, P(ws), ws.numel(), st) < 0
+    assert lib.lass_separate(eng.ctx, P(mix), P(cond), P(out), 2, 512, P(ws), ws.numel(), st) < 0
+    n = c_size_t()
+    assert lib.lass_workspace_bytes(eng.ctx, 0, 4000, byref(n)) < 0
+    # a context that was never finalized refuses to compute
+    raw = Engine(DEV)
+    assert raw.lib.lass_separate(raw.ctx, P(mix), P(cond), P(out), 2, 4000, P(ws), ws.numel(), st) < 0
+    assert raw.lib.lass_last_error(raw.ctx)
+    # unknown names / wrong shapes at upload; unknown blocks at the stage entry points
+    w = torch.zeros(3, 3)
+    shp = (__import__("ctypes").c_int64 * 2)(3, 3)
+    assert raw.lib.lass_set_param(raw.ctx, b"base.encoder_block1.conv_block1.conv1.weight", P(w), shp, 2, 0) < 0
+    assert raw.lib.lass_set_param(raw.ctx, b"not.a.parameter", P(w), shp, 2, 0) < 0
+    assert raw.lib.lass_set_param(raw.ctx, b"base.stft.conv_real.weight", P(w), shp, 2, 0) == 1  # ignored, by contract
+    with pytest.raises(_lib.LassError):
+        eng.convblock("base.no_such_block", torch.zeros(1, 32, 8, 32, device=DEV), eng.film(cond[:1]), 32)
+    # multi-window front end: unsupported window, too many windows
+    with pytest.raises(_lib.LassError):
+        eng.multi_stft(mix, [300])
+    with pytest.raises(_lib.LassError):
+        eng.multi_stft(mix, [256, 512, 1024, 2048, 256])
+    # the engine still works afterwards
+    assert torch.isfinite(eng.separate(mix, cond)).all()
+
+
 def test_long_form_clip_config5(model, oracle_sd):
     """BASELINE configs[4] input shape: one 30 s clip at 32 kHz (L = 960000, T = 6001 -> 6016) through the same
     single-STFT trunk (the reference's multi-STFT model is not runnable).  Whole-clip forward vs the oracle."""
