@@ -88,6 +88,7 @@ struct lass_ctx {
     bool wino = true;          // Winograd F(2x2,3x3) kernels for the 3x3 convs at W >= 32 (LASS_WINO=0: direct only)
     bool fuse_preconv = true;  // LASS_FUSE_PRECONV=0 materialises pre_conv's output with its own kernel
     bool fuse_pool = true;  // LASS_FUSE_POOL=0 selects the stand-alone pool kernel (A/B + parity of both paths)
+    bool fuse_catb = true;  // bf16 mode: decoder concats as blocked bf16 copies (LASS_FUSE_CATB=0: f32 concat)
     bool fuse_mask = true;  // LASS_FUSE_MASK=0 keeps after_conv + mask as their own kernel behind decoder_block6
     bool profiling = false;
     std::vector<ProfEntry> prof;
@@ -293,6 +294,16 @@ void prof_collect(lass_ctx* c) {
 // x: (B,cin,H,W) batch stride x_bs; out: batch stride out_bs (may be a channel slice of a concat buffer).
 // pool_out (optional): the block's avg-pooled output (B,cout,H/pool_h,W/2), produced by conv2's epilogue.
 // x0 (optional, encoder_block1 only): the block input is pre_conv(x0) and is formed on the fly - x is then ignored.
+// bf16 mode: a decoder's concat input (transposed-conv output | encoder skip) kept as two blocked bf16 copies in the
+// concat buffer's storage - `act` (consumer prologue applied) for conv1, `raw` for the 1x1 shortcut (ConvArgs::out_bf16_act)
+struct CatCopies {
+    void* act;
+    void* raw;
+    int noct;            // octets per clip = 2C / 8
+    const float* scale;  // conv_block2.bn1 (+ FiLM shift below) of the decoder, at concat channel 0
+    const float* shift;
+};
+
 // Output head fused into the last decoder block's conv2 (after_conv + complex ratio mask): inputs / outputs of the mask
 struct MaskHead {
     const float* mag;
@@ -305,7 +316,8 @@ struct MaskHead {
 
 int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int B, int H, int W, const float* shift,
                  float* a2, float* out, long out_bs, hipStream_t st, float* pool_out = nullptr, int pool_h = 2,
-                 const float* x0 = nullptr, const MaskHead* mh = nullptr) {
+                 const float* x0 = nullptr, const MaskHead* mh = nullptr, const CatCopies* skip_out = nullptr,
+                 const CatCopies* cat_in = nullptr) {
     const Site& s1 = c->sites[rb.s1];
     const Site& s2 = c->sites[rb.s2];
     const long HW = (long)H * W;
@@ -326,6 +338,9 @@ int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int
     void* a2_hi = a2;
     void* a2_lo = c->compute_mode == LASS_COMPUTE_BF16X3 ? (void*)((char*)a2 + (size_t)B * rb.cout * HW * 2) : nullptr;
     if (bf1) { p.out_bf16 = a2_hi; p.out_bf16_lo = a2_lo; }
+    if ((skip_out || cat_in) && (!bf1 || c->compute_mode != LASS_COMPUTE_BF16))
+        return fail(c, LASS_ERR_STATE, "blocked bf16 concat copies need the bf16 kernels");
+    if (cat_in) p.in_bf16 = cat_in->act;
     const bool wino1 = !bf1 && c->wino && rb.u1 && lass_wino_supported(p);
     {
         ProfScope ps(c, st, P_CONV3X3);
@@ -350,6 +365,13 @@ int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int
     q.w_bf16 = rb.b2; q.w2_bf16 = rb.bsc16; q.w_bf16_lo = rb.b2l; q.w2_bf16_lo = rb.bscl;
     const bool bf2 = bf1;  // conv1 and conv2 of a block share shape and mode: both or neither
     if (bf2) { q.in_bf16 = a2_hi; q.in_bf16_lo = a2_lo; }
+    if (cat_in) q.in2_bf16 = cat_in->raw;
+    if (skip_out) {  // the skip goes out as the two blocked copies (concat channels [C, 2C)) instead of f32
+        q.out = nullptr;
+        q.out_bf16 = skip_out->raw; q.out_bf16_act = skip_out->act;
+        q.out_oct0 = rb.cout / 8; q.out_noct = skip_out->noct;
+        q.act_scale = skip_out->scale + rb.cout; q.act_shift = skip_out->shift + rb.cout; q.act_shift_bs = c->n_shift;
+    }
     const bool wino2 = !bf2 && c->wino && rb.u2 && lass_wino_supported(q);
     ProfScope ps(c, st, P_CONV3X3);
     if (rb.cin == rb.cout) {
@@ -377,7 +399,7 @@ int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int
 }
 
 int run_upconv(lass_ctx* c, int di, const float* x, int B, int h, int w, const float* shift, float* out, long out_bs,
-               hipStream_t st) {
+               hipStream_t st, const CatCopies* cb = nullptr) {
     const DecSpec& d = kDec[di];
     const Site& s = c->sites[c->dec_site[di]];
     ConvArgs p;
@@ -387,6 +409,13 @@ int run_upconv(lass_ctx* c, int di, const float* x, int B, int h, int w, const f
     p.pro_scale = c->bn_scale + s.off; p.pro_shift = shift + s.off; p.pro_shift_bs = c->n_shift;
     p.out = out; p.out_bs = out_bs; p.B = B; p.H = h; p.W = w; p.up_h = d.uh;
     p.w_bf16 = c->up16[di]; p.w_bf16_lo = c->up16l[di];
+    if (cb) {  // concat channels [0, C) as the two blocked copies instead of f32
+        if (c->compute_mode != LASS_COMPUTE_BF16 || !p.w_bf16 || !lass_bf16_supported(p))
+            return fail(c, LASS_ERR_STATE, "blocked bf16 concat copies need the bf16 kernels");
+        p.out = nullptr;
+        p.out_bf16 = cb->raw; p.out_bf16_act = cb->act; p.out_oct0 = 0; p.out_noct = cb->noct;
+        p.act_scale = cb->scale; p.act_shift = cb->shift; p.act_shift_bs = c->n_shift;
+    }
     ProfScope ps(c, st, P_TCONV);
     if (c->compute_mode != LASS_COMPUTE_F32 && p.w_bf16 && lass_bf16_supported(p))
         HIP_TRY(c, lass_launch_conv_bf16(TCONV_ACT, p, st));
@@ -492,6 +521,7 @@ int lass_create(lass_ctx** out, int device_id) {
     if (const char* e = getenv("LASS_WINO")) c->wino = atoi(e) != 0;
     if (const char* e = getenv("LASS_FUSE_POOL")) c->fuse_pool = atoi(e) != 0;
     if (const char* e = getenv("LASS_FUSE_MASK")) c->fuse_mask = atoi(e) != 0;
+    if (const char* e = getenv("LASS_FUSE_CATB")) c->fuse_catb = atoi(e) != 0;
     if (const char* e = getenv("LASS_FUSE_PRECONV")) c->fuse_preconv = atoi(e) != 0;
     c->prof.resize(P_COUNT);
     for (int i = 0; i < P_COUNT; ++i) c->prof[i].name = kProfNames[i];
@@ -842,6 +872,22 @@ int lass_separate(lass_ctx* c, const float* mixture, const float* condition, flo
         HIP_TRY(c, lass_launch_preconv(F(pl.x0), rawp(c, "base.pre_conv.weight"), rawp(c, "base.pre_conv.bias"), B,
                                        kPreCh, (long)Tp * LASS_FCROP, F(pl.xpre), st));
     }
+    // bf16 mode: decoders 2-6 (2x2 up-sampling) take their concat as blocked bf16 copies written by the producers
+    CatCopies cb[6];
+    bool use_cb[6] = {false, false, false, false, false, false};
+    for (int d = 1; d < 6; ++d) {
+        const int e = 5 - d;
+        const ResBlock& rd = c->dec[d];
+        const long hw = (long)pl.eh[e] * pl.ew[e];
+        use_cb[d] = c->fuse_catb && c->compute_mode == LASS_COMPUTE_BF16 && kDec[d].uh == 2 && kDec[d].uw == 2 && c->fuse_pool &&
+                    (pl.eh[e] % kEnc[e].dh) == 0 && rd.cout % 16 == 0 && rd.b1 && rd.b2 && rd.bsc16 && c->up16[d] &&
+                    c->enc[e].b1 && c->enc[e].b2 && (e != 0 || fuse_pre);
+        cb[d].act = F(pl.cat[d]);
+        cb[d].raw = (char*)F(pl.cat[d]) + (size_t)B * 2 * rd.cout * hw * 2;
+        cb[d].noct = 2 * rd.cout / 8;
+        cb[d].scale = c->bn_scale + c->sites[rd.s1].off;
+        cb[d].shift = shift + c->sites[rd.s1].off;
+    }
     // ---- encoder (resunet.py:556-562) -------------------------------------------------------------------------
     const float* x = F(pl.xpre);
     for (int i = 0; i < 7; ++i) {
@@ -861,7 +907,8 @@ int lass_separate(lass_ctx* c, const float* mixture, const float* condition, flo
         const bool fuse_pool = i < 6 && c->fuse_pool && (H % kEnc[i].dh) == 0;
         r = run_resblock(c, rb, x, rb.cin * HW, B, H, W, shift, F(pl.a2), o, o_bs, st,
                          fuse_pool ? F(pl.pool[i]) : nullptr, kEnc[i].dh,
-                         (i == 0 && fuse_pre) ? F(pl.x0) : nullptr);
+                         (i == 0 && fuse_pre) ? F(pl.x0) : nullptr, nullptr,
+                         (i < 5 && use_cb[5 - i]) ? &cb[5 - i] : nullptr);
         if (r) return r;
         if (i < 6) {
             if (!fuse_pool) {
@@ -881,13 +928,14 @@ int lass_separate(lass_ctx* c, const float* mixture, const float* condition, flo
         const long HW = (long)H * W;
         const int h = H / kDec[d].uh, w = W / kDec[d].uw;
         const ResBlock& rb = c->dec[d];
-        r = run_upconv(c, d, x, B, h, w, shift, F(pl.cat[d]), 2 * rb.cout * HW, st);
+        r = run_upconv(c, d, x, B, h, w, shift, F(pl.cat[d]), 2 * rb.cout * HW, st, use_cb[d] ? &cb[d] : nullptr);
         if (r) return r;
         // decoder_block6 (32 channels at the full 512-bin resolution): after_conv + mask run in conv2's epilogue
         const MaskHead head{F(pl.mag), F(pl.cosv), F(pl.sinv), F(pl.oreal), F(pl.oimag), T};
         fused_head = d == 5 && c->fuse_mask && rb.cout == 32 && rb.cin != rb.cout && W == LASS_FCROP;
         r = run_resblock(c, rb, F(pl.cat[d]), 2 * rb.cout * HW, B, H, W, shift, F(pl.a2), F(pl.decout[d]),
-                         rb.cout * HW, st, nullptr, 2, nullptr, fused_head ? &head : nullptr);
+                         rb.cout * HW, st, nullptr, 2, nullptr, fused_head ? &head : nullptr, nullptr,
+                         use_cb[d] ? &cb[d] : nullptr);
         if (r) return r;
         x = F(pl.decout[d]);
     }

@@ -255,9 +255,11 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
     static_assert(!RESPRE || RES_PF, "x0-derived residual needs the register-prefetch path");
     constexpr bool INBF = (FLAGS & F_INBF16) != 0;    // phase A reads the blocked bf16 intermediate by LDS-DMA
     using PA = Phase16<TAPS, NCO, NPX, PW, PRO, SPLIT, PRE, INBF>;
-    using PB = Phase16<1, NCO, NPX, PW, false, SPLIT>;
+    constexpr bool IN2BF = (FLAGS & F_IN2BF16) != 0;  // phase B reads the blocked bf16 raw copy by LDS-DMA
+    using PB = Phase16<1, NCO, NPX, PW, false, SPLIT, false, IN2BF>;
     constexpr int PA_LDS = INBF ? 2 * PA::IN_U4 + PA::W_U4 : PA::LDS_U4;  // INBF: two image buffers + one weight region
-    constexpr int LDS_U4 = HASB ? MaxU<PA_LDS, PB::LDS_U4>::v : PA_LDS;
+    constexpr int PB_LDS = IN2BF ? 2 * PB::IN_U4 + PB::W_U4 : PB::LDS_U4;
+    constexpr int LDS_U4 = HASB ? MaxU<PA_LDS, PB_LDS>::v : PA_LDS;
     constexpr int PH = PA::PH, WROWS = PA::WROWS, PHT = PA::PHT, NT = PA::NT;
     constexpr bool MASK = (FLAGS & F_MASK) != 0;
     constexpr int NTAB = (EPI ? 2 * NT : 0) + (BIAS ? NT : 0) + (MASK ? 100 : 0);
@@ -282,7 +284,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
     const int nA = p.Cin / KB;
     const int nB = HASB ? p.Cin2 / KB : 0;
     const float* in_b = INBF ? nullptr : p.in + (size_t)b * p.in_bs;
-    const float* in2_b = HASB ? p.in2 + (size_t)b * p.in2_bs : nullptr;
+    const float* in2_b = (HASB && !IN2BF) ? p.in2 + (size_t)b * p.in2_bs : nullptr;
     const float* sc = PRO ? p.pro_scale : nullptr;
     const float* sh = PRO ? p.pro_shift + (size_t)b * p.pro_shift_bs : nullptr;
     const uint4* wa = reinterpret_cast<const uint4*>(p.w_bf16) + n0;    // [chunk][tap][octet][Cout] 16-B units
@@ -305,7 +307,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
     const __amdgpu_buffer_rsrc_t in_rs = rs(in_b, INBF ? 0 : (long)(PRE ? 1 : p.Cin) * HW * 4);
     const __amdgpu_buffer_rsrc_t wa_rs = rs(wa, ((long)(p.Cin / KB) * TAPS * 2 * p.Nw - n0) * 16);
     const __amdgpu_buffer_rsrc_t wal_rs = SPLIT == 2 ? rs(wa_lo, ((long)(p.Cin / KB) * TAPS * 2 * p.Nw - n0) * 16) : wa_rs;
-    const __amdgpu_buffer_rsrc_t in2_rs = HASB ? rs(in2_b, (long)p.Cin2 * HW * 4) : in_rs;
+    const __amdgpu_buffer_rsrc_t in2_rs = (HASB && !IN2BF) ? rs(in2_b, (long)p.Cin2 * HW * 4) : in_rs;
     const __amdgpu_buffer_rsrc_t wb_rs = HASB ? rs(wb2, ((long)(p.Cin2 / KB) * 2 * p.Nw - n0) * 16) : wa_rs;
     const __amdgpu_buffer_rsrc_t wbl_rs = (HASB && SPLIT == 2) ? rs(wb2_lo, ((long)(p.Cin2 / KB) * 2 * p.Nw - n0) * 16) : wb_rs;
     auto loadA = [&](int c) {
@@ -378,9 +380,9 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
     }
     float rtmp[RES_PF ? NPX : 1][16];
     if (HASB) {
-        pb.init(tid, y0, x0, p.H, p.W);
+        if (!IN2BF) pb.init(tid, y0, x0, p.H, p.W);
         pb.init_w(tid, p.Nw);
-        loadB(0);
+        if (!IN2BF) loadB(0);
     }
     if (RES_PF) {
 #pragma unroll
@@ -401,7 +403,35 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
         }
     }
     if (!INBF) PA::compute(lds4, wl_a, acc, lane, wave);  // last chunk of phase A (the INBF loop contracts all of them)
-    if (HASB) {
+    if (HASB && IN2BF) {
+        // same schedule as the INBF main phase: image by LDS-DMA into alternating buffers, weights through registers
+        uint4* wl_b = lds4 + 2 * PB::IN_U4;
+        const long plane2 = (long)(p.Cin2 / 8) * HW * 16;
+        const v4i32 r_rs = make_rsrc_words(reinterpret_cast<const char*>(p.in2_bf16) + (size_t)b * plane2, (unsigned)plane2);
+        const unsigned img0 = (unsigned)(size_t)(__attribute__((address_space(3))) uint4*)lds4;
+        const unsigned img1 = img0 + (unsigned)(PB::IN_U4 * 16);
+        pb.init_dma(lane, wave, y0, x0, p.H, p.W);
+        __syncthreads();  // phase A has finished with the LDS
+        pb.issue_dma(r_rs, r_rs, 0u, img0, wave);
+        loadB(0);
+        pb.store(lds4, wl_b, tid);
+        wait_vmcnt<0>();
+        __syncthreads();
+        for (int ch = 0; ch < nB; ++ch) {
+            const bool more = ch + 1 < nB;
+            if (more) {
+                pb.issue_dma(r_rs, r_rs, (unsigned)((ch + 1) * 2 * HW) * 16u, (ch & 1) ? img0 : img1, wave);
+                loadB(ch + 1);
+            }
+            PB::compute(lds4 + ((ch & 1) ? PB::IN_U4 : 0), wl_b, acc, lane, wave);
+            __syncthreads();
+            if (more) {
+                pb.store(lds4, wl_b, tid);
+                wait_vmcnt<0>();
+            }
+            __syncthreads();
+        }
+    } else if (HASB) {
         uint4* wl_b = lds4 + PB::IN_U4;
         __syncthreads();
         pb.store(lds4, wl_b, tid);
@@ -445,10 +475,15 @@ template <int TAPS, int NCO, int NPX, int PW, int FLAGS>
 hipError_t launch_bf16_one(const ConvArgs& p, hipStream_t stream) {
     constexpr int PHT = 4 * NPX * (32 / PW);
     dim3 grid((p.W / PW) * ((p.H + PHT - 1) / PHT), p.N / (32 * NCO), p.B);
-    if (p.w_bf16_lo)
-        hipLaunchKernelGGL((conv_bf16_kernel<TAPS, NCO, NPX, PW, FLAGS, 2>), grid, dim3(NTHREADS), 0, stream, p);
-    else
+    if constexpr ((FLAGS & F_NOSPLIT) != 0) {
+        if (p.w_bf16_lo) return hipErrorInvalidValue;
         hipLaunchKernelGGL((conv_bf16_kernel<TAPS, NCO, NPX, PW, FLAGS, 1>), grid, dim3(NTHREADS), 0, stream, p);
+    } else {
+        if (p.w_bf16_lo)
+            hipLaunchKernelGGL((conv_bf16_kernel<TAPS, NCO, NPX, PW, FLAGS, 2>), grid, dim3(NTHREADS), 0, stream, p);
+        else
+            hipLaunchKernelGGL((conv_bf16_kernel<TAPS, NCO, NPX, PW, FLAGS, 1>), grid, dim3(NTHREADS), 0, stream, p);
+    }
     return hipGetLastError();
 }
 
@@ -478,7 +513,11 @@ hipError_t lass_launch_conv_bf16(ConvKind kind, const ConvArgs& p, hipStream_t s
     if (p.w_bf16_lo && ((p.in_bf16 && !p.in_bf16_lo) || (p.out_bf16 && !p.out_bf16_lo))) return hipErrorInvalidValue;
     switch (kind) {
         case CONV1_ACT:
-            if (!p.pro_scale || !p.pro_shift || !p.epi_scale || !p.epi_shift) return hipErrorInvalidValue;
+            if ((!p.in_bf16 && (!p.pro_scale || !p.pro_shift)) || !p.epi_scale || !p.epi_shift) return hipErrorInvalidValue;
+            if (p.in_bf16) {  // decoder conv1 fed by the activated blocked copy of the concat: no prologue left to apply
+                if (!p.out_bf16) return hipErrorInvalidValue;
+                return launch_bf16<9, F_EPIACT | F_OUTBF16 | F_INBF16 | F_NOSPLIT>(p, stream);
+            }
             if (p.out_bf16) return launch_bf16<9, F_PRO | F_EPIACT | F_OUTBF16>(p, stream);
             return launch_bf16<9, F_PRO | F_EPIACT>(p, stream);
         case CONV2_IDENT:
@@ -486,18 +525,24 @@ hipError_t lass_launch_conv_bf16(ConvKind kind, const ConvArgs& p, hipStream_t s
             if (p.in_bf16) return launch_bf16<9, F_RES | F_INBF16>(p, stream);
             return launch_bf16<9, F_RES>(p, stream);
         case CONV2_SHORTCUT:
-            if (!p.in2 || !p.w2_bf16 || !p.bias || p.Cin2 % 16 != 0 || (p.w_bf16_lo && !p.w2_bf16_lo))
+            if ((!p.in2 && !p.in2_bf16) || !p.w2_bf16 || !p.bias || p.Cin2 % 16 != 0 || (p.w_bf16_lo && !p.w2_bf16_lo))
                 return hipErrorInvalidValue;
             if (p.mask_re) {  // fused output head: decoder_block6 geometry only
                 if (p.N != 32 || p.W != LASS_FCROP || !p.in_bf16 || !p.mask_w || !p.mask_b || !p.mask_mag || !p.mask_cos ||
                     !p.mask_sin || !p.mask_im || p.mask_T <= 0 || p.mask_T > p.H)
                     return hipErrorInvalidValue;
+                if (p.in2_bf16)
+                    return launch_bf16_one<9, 1, 2, 32, F_PHASEB | F_BIAS | F_INBF16 | F_IN2BF16 | F_MASK | F_NOSPLIT>(p, stream);
                 return launch_bf16_one<9, 1, 2, 32, F_PHASEB | F_BIAS | F_INBF16 | F_MASK>(p, stream);
             }
+            if (p.in_bf16 && p.in2_bf16) return launch_bf16<9, F_PHASEB | F_BIAS | F_INBF16 | F_IN2BF16 | F_NOSPLIT>(p, stream);
+            if (p.in_bf16 && p.out_bf16) return launch_bf16<9, F_PHASEB | F_BIAS | F_INBF16 | F_OUTBF16 | F_NOSPLIT>(p, stream);
             if (p.in_bf16) return launch_bf16<9, F_PHASEB | F_BIAS | F_INBF16>(p, stream);
             return launch_bf16<9, F_PHASEB | F_BIAS>(p, stream);
         case TCONV_ACT:
             if (!p.pro_scale || !p.pro_shift || (p.up_h != 1 && p.up_h != 2)) return hipErrorInvalidValue;
+            if (p.out_bf16 && (p.up_h != 2 || !p.out_bf16_act || !p.act_scale || !p.act_shift || p.out_noct <= 0 || p.N % 32 != 0))
+                return hipErrorInvalidValue;
             return launch_bf16<1, F_PRO | F_TCONV>(p, stream);
         case CONV1_ACT_PRE:  // encoder_block1 at full resolution: 32 -> 32 channels, W a multiple of 32
             if (!p.pro_scale || !p.pro_shift || !p.epi_scale || !p.epi_shift || !p.pre_w || !p.pre_b || p.N != 32 ||
@@ -507,6 +552,8 @@ hipError_t lass_launch_conv_bf16(ConvKind kind, const ConvArgs& p, hipStream_t s
             return launch_bf16_one<9, 1, 2, 32, F_PRO | F_EPIACT | F_PRECONV>(p, stream);
         case CONV2_IDENT_PRE:
             if (!p.res || !p.pre_w || !p.pre_b || p.N != 32 || p.W % 32 != 0) return hipErrorInvalidValue;
+            if (p.in_bf16 && p.out_bf16)
+                return launch_bf16_one<9, 1, 2, 32, F_RES | F_RESPRE | F_INBF16 | F_OUTBF16 | F_NOSPLIT>(p, stream);
             if (p.in_bf16) return launch_bf16_one<9, 1, 2, 32, F_RES | F_RESPRE | F_INBF16>(p, stream);
             return launch_bf16_one<9, 1, 2, 32, F_RES | F_RESPRE>(p, stream);
         default:

@@ -18,6 +18,8 @@ constexpr int F_PRECONV = 64;   // input is the 1-channel x0; channel c = pre_w[
 constexpr int F_RESPRE = 128;   // with F_RES: the residual is pre_w[n]*x0 + pre_b[n] (never materialised)
 constexpr int F_OUTBF16 = 256;  // bf16 kernels: the output is the blocked bf16 intermediate [C/8][H][W][8] (+ lo plane)
 constexpr int F_MASK = 1024;    // epilogue = after_conv + complex ratio mask (see ConvArgs::mask_*); no tensor output
+constexpr int F_IN2BF16 = 4096;  // bf16 kernels: phase B (shortcut) reads the blocked bf16 raw copy by LDS-DMA
+constexpr int F_NOSPLIT = 8192;  // bf16 mode only (no split-operand instantiation)
 constexpr int F_INBF16 = 512;   // bf16 kernels: phase A reads that intermediate by LDS-DMA
 
 constexpr int NTHREADS = 256;
@@ -59,6 +61,46 @@ __device__ __forceinline__ void tconv_store(const ConvArgs& p, f32x16 (&acc)[NCO
     const int uhw = p.up_h * 2;
     const size_t oHW = (size_t)HW * uhw;
     const int oW = p.W * 2;
+    if (p.out_bf16) {
+        // Blocked bf16 outputs (up_h == 2, host-checked): a 32-row co-tile is 8 channels x 4 sub-pixels = one octet; the
+        // khalf pair holds all of it (channel 2g + khalf, sub-pixel i in register 4g + i).  The pair swaps halves so that
+        // lane khalf owns output row a = khalf with all 8 channels, then stores two adjacent 16-B units (bb = 0, 1).
+        typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+        const size_t clip = (size_t)b * p.out_noct * oHW;
+#pragma unroll
+        for (int co = 0; co < NCO; ++co)
+#pragma unroll
+            for (int px = 0; px < NPX; ++px) {
+                const int y = y0 + wave * WROWS + px * PH + ty;
+                float ch[2][8];  // [bb][channel in octet]
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int bb = 0; bb < 2; ++bb) {
+                        const float lo_a = acc[co][px][4 * g + bb], hi_a = acc[co][px][4 * g + 2 + bb];  // a = 0 / 1
+                        const float keep = khalf ? hi_a : lo_a, send = khalf ? lo_a : hi_a;
+                        const float other = __shfl_xor(send, 32, 64);
+                        ch[bb][2 * g] = khalf ? other : keep;      // even channel: from the khalf = 0 lane
+                        ch[bb][2 * g + 1] = khalf ? keep : other;  // odd channel: from the khalf = 1 lane
+                    }
+                if (y >= p.H) continue;
+                const int oct = (n0 + co * 32) / 32;  // octet of this co-tile among the launch's output channels
+                const size_t unit = clip + (size_t)(p.out_oct0 + oct) * oHW + (size_t)(y * 2 + khalf) * oW + x * 2;
+#pragma unroll
+                for (int bb = 0; bb < 2; ++bb) {
+                    bf16x8 raw, act;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        raw[k] = (__bf16)ch[bb][k];
+                        const int c = oct * 8 + k;
+                        act[k] = (__bf16)leaky(ch[bb][k] * p.act_scale[c] + p.act_shift[(size_t)b * p.act_shift_bs + c]);
+                    }
+                    *reinterpret_cast<bf16x8*>(reinterpret_cast<char*>(p.out_bf16) + (unit + bb) * 16) = raw;
+                    *reinterpret_cast<bf16x8*>(reinterpret_cast<char*>(p.out_bf16_act) + (unit + bb) * 16) = act;
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int co = 0; co < NCO; ++co)
 #pragma unroll
@@ -129,20 +171,28 @@ __device__ __forceinline__ void store_tile(const ConvArgs& p, f32x16 (&acc)[NCO]
                 // blocked bf16 layout: unit (octet, y, x) = 16 B = 8 channels; this lane holds channels 4*khalf..+3 of the
                 // four octets g of its 32-cout tile -> one 8-byte store per octet (the khalf pair completes the unit)
                 if (y < p.H) {
-                    const size_t clip = (size_t)b * (p.N / 8) * HW;
+                    const int noct = p.out_noct ? p.out_noct : p.N / 8;
+                    const size_t clip = (size_t)b * noct * HW;
                     typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const size_t unit = clip + (size_t)((n0 + co * 32) / 8 + g) * HW + (size_t)y * p.W + x;
-                        bf16x4 hi, lo;
+                        const size_t unit = clip + (size_t)(p.out_oct0 + (n0 + co * 32) / 8 + g) * HW + (size_t)y * p.W + x;
+                        bf16x4 hi, lo, ac;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-                            hi[i] = (__bf16)val[px][4 * g + i];
-                            lo[i] = (__bf16)(val[px][4 * g + i] - (float)hi[i]);
+                            const float v = val[px][4 * g + i];
+                            hi[i] = (__bf16)v;
+                            lo[i] = (__bf16)(v - (float)hi[i]);
+                            if (p.out_bf16_act) {
+                                const int n = n0 + co * 32 + 8 * g + 4 * khalf + i;
+                                ac[i] = (__bf16)leaky(v * p.act_scale[n] + p.act_shift[(size_t)b * p.act_shift_bs + n]);
+                            }
                         }
                         *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(p.out_bf16) + unit * 16 + khalf * 8) = hi;
                         if (p.out_bf16_lo)
                             *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(p.out_bf16_lo) + unit * 16 + khalf * 8) = lo;
+                        if (p.out_bf16_act)
+                            *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(p.out_bf16_act) + unit * 16 + khalf * 8) = ac;
                     }
                 }
             } else if (y < p.H) {

@@ -49,6 +49,16 @@ struct ConvArgs {
     void* out_bf16_lo = nullptr;
     const void* in_bf16 = nullptr;
     const void* in_bf16_lo = nullptr;
+    // bf16 mode, decoder inputs: the concat (transposed-conv output | encoder skip) is kept as TWO blocked bf16 copies
+    // instead of f32 - `raw` for the 1x1 shortcut and `act` = leaky(v*act_scale[c] + act_shift[b][c]) (the consumer's
+    // BN+FiLM prologue) for conv1.  Producers write octets [out_oct0, out_oct0 + N/8) of out_noct octets per clip.
+    void* out_bf16_act = nullptr;
+    const float* act_scale = nullptr;   // indexed by this launch's output channel
+    const float* act_shift = nullptr;   // [B][act_shift_bs]
+    int act_shift_bs = 0;
+    int out_oct0 = 0;
+    int out_noct = 0;                   // 0: N / 8
+    const void* in2_bf16 = nullptr;     // phase B (1x1 shortcut) input as the blocked bf16 raw copy
     const float* pre_w = nullptr;  // pre_conv (1x1, 1 -> 32) weight / bias for the *_PRE kinds
     const float* pre_b = nullptr;
     // fused output head (decoder_block6.conv2 only, N == 32, W == 512): after_conv (1x1, 32 -> 3, + bias) and the complex

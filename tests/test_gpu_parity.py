@@ -426,7 +426,7 @@ def test_fusion_switches_agree(synthetic_sd, monkeypatch):
 
 
 # ---- BASELINE configs[2]: bf16-MFMA convolutions (reduced precision by design; its own tolerances) --------------------
-def test_bf16_mode_convblock_and_waveform(synthetic_sd, oracle_sd):
+def test_bf16_mode_convblock_and_waveform(synthetic_sd, oracle_sd, monkeypatch):
     """Operands of the 3x3 convs are rounded to bf16 (8-bit mantissa, ~4e-3 relative each): per-block outputs must
     agree with the f32 oracle to ~1e-2 relative RMS and the end-to-end waveform to ~5e-2 relative RMS; SDR against the
     oracle's waveform must exceed 25 dB.  (The f32 path is held to 2e-6.)"""
@@ -459,6 +459,14 @@ def test_bf16_mode_convblock_and_waveform(synthetic_sd, oracle_sd):
     rel = _relerr(out, ref)
     print("bf16 waveform relative RMS error", rel)
     assert rel < 5e-2, rel
+    # the blocked bf16 concat copies (default) round exactly what the f32-concat path rounds while staging: same waveform
+    monkeypatch.setenv("LASS_FUSE_CATB", "0")
+    m2 = ResUNet30(1, 1, 512)
+    m2.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synthetic_sd.items()})
+    out2 = m2.to(DEV).eval().set_compute_dtype("bf16")(
+        {"mixture": torch.from_numpy(mix)[:, None, :].to(DEV), "condition": torch.from_numpy(c2).to(DEV)})["waveform"]
+    monkeypatch.delenv("LASS_FUSE_CATB")
+    assert _relerr(out2, out) < 1e-5
 
 
 def test_bf16x3_split_mode_is_f32_accurate(synthetic_sd, oracle_sd, golden_dir):
