@@ -317,7 +317,7 @@ struct MaskHead {
 int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int B, int H, int W, const float* shift,
                  float* a2, float* out, long out_bs, hipStream_t st, float* pool_out = nullptr, int pool_h = 2,
                  const float* x0 = nullptr, const MaskHead* mh = nullptr, const CatCopies* skip_out = nullptr,
-                 const CatCopies* cat_in = nullptr) {
+                 const CatCopies* cat_in = nullptr, const Site* act_out = nullptr) {
     const Site& s1 = c->sites[rb.s1];
     const Site& s2 = c->sites[rb.s2];
     const long HW = (long)H * W;
@@ -366,6 +366,12 @@ int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int
     const bool bf2 = bf1;  // conv1 and conv2 of a block share shape and mode: both or neither
     if (bf2) { q.in_bf16 = a2_hi; q.in_bf16_lo = a2_lo; }
     if (cat_in) q.in2_bf16 = cat_in->raw;
+    if (act_out) {  // bf16 mode: the block output goes to the next transposed conv only - written as ONE blocked bf16
+                    // tensor with that conv's BN+FiLM+leaky prologue already applied (in `out`'s storage)
+        if (!bf2 || c->compute_mode != LASS_COMPUTE_BF16) return fail(c, LASS_ERR_STATE, "activated bf16 output needs the bf16 kernels");
+        q.out_bf16 = out; q.out = nullptr; q.out_oct0 = 0; q.out_noct = 0;
+        q.epi_scale = c->bn_scale + act_out->off; q.epi_shift = shift + act_out->off; q.epi_shift_bs = c->n_shift;
+    }
     if (skip_out) {  // the skip goes out as the two blocked copies (concat channels [C, 2C)) instead of f32
         q.out = nullptr;
         q.out_bf16 = skip_out->raw; q.out_bf16_act = skip_out->act;
@@ -399,7 +405,7 @@ int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int
 }
 
 int run_upconv(lass_ctx* c, int di, const float* x, int B, int h, int w, const float* shift, float* out, long out_bs,
-               hipStream_t st, const CatCopies* cb = nullptr) {
+               hipStream_t st, const CatCopies* cb = nullptr, bool x_is_act_bf16 = false) {
     const DecSpec& d = kDec[di];
     const Site& s = c->sites[c->dec_site[di]];
     ConvArgs p;
@@ -409,6 +415,11 @@ int run_upconv(lass_ctx* c, int di, const float* x, int B, int h, int w, const f
     p.pro_scale = c->bn_scale + s.off; p.pro_shift = shift + s.off; p.pro_shift_bs = c->n_shift;
     p.out = out; p.out_bs = out_bs; p.B = B; p.H = h; p.W = w; p.up_h = d.uh;
     p.w_bf16 = c->up16[di]; p.w_bf16_lo = c->up16l[di];
+    if (x_is_act_bf16) {  // the producer already applied this conv's prologue and wrote blocked bf16
+        if (c->compute_mode != LASS_COMPUTE_BF16 || !p.w_bf16 || !lass_bf16_supported(p))
+            return fail(c, LASS_ERR_STATE, "activated bf16 input needs the bf16 kernels");
+        p.in_bf16 = x;
+    }
     if (cb) {  // concat channels [0, C) as the two blocked copies instead of f32
         if (c->compute_mode != LASS_COMPUTE_BF16 || !p.w_bf16 || !lass_bf16_supported(p))
             return fail(c, LASS_ERR_STATE, "blocked bf16 concat copies need the bf16 kernels");
@@ -921,6 +932,7 @@ int lass_separate(lass_ctx* c, const float* mixture, const float* condition, flo
         }
     }
     // ---- decoder (resunet.py:563-568) -------------------------------------------------------------------------
+    bool x_act = false;  // x (input of the next transposed conv) is an activated blocked bf16 tensor
     bool fused_head = false;
     for (int d = 0; d < 6; ++d) {
         const int e = 5 - d;
@@ -928,14 +940,19 @@ int lass_separate(lass_ctx* c, const float* mixture, const float* condition, flo
         const long HW = (long)H * W;
         const int h = H / kDec[d].uh, w = W / kDec[d].uw;
         const ResBlock& rb = c->dec[d];
-        r = run_upconv(c, d, x, B, h, w, shift, F(pl.cat[d]), 2 * rb.cout * HW, st, use_cb[d] ? &cb[d] : nullptr);
+        r = run_upconv(c, d, x, B, h, w, shift, F(pl.cat[d]), 2 * rb.cout * HW, st, use_cb[d] ? &cb[d] : nullptr, x_act);
+        if (r) return r;
+        // this decoder's output feeds only the next transposed conv: hand it over activated, as blocked bf16
+        const bool act_next = d < 5 && c->fuse_catb && c->compute_mode == LASS_COMPUTE_BF16 && rb.b1 && rb.b2 && rb.bsc16 &&
+                              rb.cout % 16 == 0 && c->up16[d + 1];
+        x_act = act_next;
         if (r) return r;
         // decoder_block6 (32 channels at the full 512-bin resolution): after_conv + mask run in conv2's epilogue
         const MaskHead head{F(pl.mag), F(pl.cosv), F(pl.sinv), F(pl.oreal), F(pl.oimag), T};
         fused_head = d == 5 && c->fuse_mask && rb.cout == 32 && rb.cin != rb.cout && W == LASS_FCROP;
         r = run_resblock(c, rb, F(pl.cat[d]), 2 * rb.cout * HW, B, H, W, shift, F(pl.a2), F(pl.decout[d]),
                          rb.cout * HW, st, nullptr, 2, nullptr, fused_head ? &head : nullptr, nullptr,
-                         use_cb[d] ? &cb[d] : nullptr);
+                         use_cb[d] ? &cb[d] : nullptr, act_next ? &c->sites[c->dec_site[d + 1]] : nullptr);
         if (r) return r;
         x = F(pl.decout[d]);
     }

@@ -535,14 +535,23 @@ hipError_t lass_launch_conv_bf16(ConvKind kind, const ConvArgs& p, hipStream_t s
                     return launch_bf16_one<9, 1, 2, 32, F_PHASEB | F_BIAS | F_INBF16 | F_IN2BF16 | F_MASK | F_NOSPLIT>(p, stream);
                 return launch_bf16_one<9, 1, 2, 32, F_PHASEB | F_BIAS | F_INBF16 | F_MASK>(p, stream);
             }
+            if (p.in_bf16 && p.out_bf16 && !p.out_bf16_act) {
+                // decoder output handed to the next transposed conv as ONE activated blocked bf16 tensor (its BN+FiLM+leaky
+                // prologue applied here as the epilogue activation)
+                if (!p.epi_scale || !p.epi_shift) return hipErrorInvalidValue;
+                if (p.in2_bf16)
+                    return launch_bf16<9, F_PHASEB | F_BIAS | F_INBF16 | F_IN2BF16 | F_EPIACT | F_OUTBF16 | F_NOSPLIT>(p, stream);
+                return launch_bf16<9, F_PHASEB | F_BIAS | F_INBF16 | F_EPIACT | F_OUTBF16 | F_NOSPLIT>(p, stream);
+            }
             if (p.in_bf16 && p.in2_bf16) return launch_bf16<9, F_PHASEB | F_BIAS | F_INBF16 | F_IN2BF16 | F_NOSPLIT>(p, stream);
             if (p.in_bf16 && p.out_bf16) return launch_bf16<9, F_PHASEB | F_BIAS | F_INBF16 | F_OUTBF16 | F_NOSPLIT>(p, stream);
             if (p.in_bf16) return launch_bf16<9, F_PHASEB | F_BIAS | F_INBF16>(p, stream);
             return launch_bf16<9, F_PHASEB | F_BIAS>(p, stream);
         case TCONV_ACT:
-            if (!p.pro_scale || !p.pro_shift || (p.up_h != 1 && p.up_h != 2)) return hipErrorInvalidValue;
+            if ((!p.in_bf16 && (!p.pro_scale || !p.pro_shift)) || (p.up_h != 1 && p.up_h != 2)) return hipErrorInvalidValue;
             if (p.out_bf16 && (p.up_h != 2 || !p.out_bf16_act || !p.act_scale || !p.act_shift || p.out_noct <= 0 || p.N % 32 != 0))
                 return hipErrorInvalidValue;
+            if (p.in_bf16) return launch_bf16<1, F_TCONV | F_INBF16 | F_NOSPLIT>(p, stream);  // input already activated bf16
             return launch_bf16<1, F_PRO | F_TCONV>(p, stream);
         case CONV1_ACT_PRE:  // encoder_block1 at full resolution: 32 -> 32 channels, W a multiple of 32
             if (!p.pro_scale || !p.pro_shift || !p.epi_scale || !p.epi_shift || !p.pre_w || !p.pre_b || p.N != 32 ||
