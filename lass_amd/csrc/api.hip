@@ -317,7 +317,7 @@ struct MaskHead {
 int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int B, int H, int W, const float* shift,
                  float* a2, float* out, long out_bs, hipStream_t st, float* pool_out = nullptr, int pool_h = 2,
                  const float* x0 = nullptr, const MaskHead* mh = nullptr, const CatCopies* skip_out = nullptr,
-                 const CatCopies* cat_in = nullptr, const Site* act_out = nullptr) {
+                 const CatCopies* cat_in = nullptr, const Site* act_out = nullptr, const CatCopies* pool_copies = nullptr) {
     const Site& s1 = c->sites[rb.s1];
     const Site& s2 = c->sites[rb.s2];
     const long HW = (long)H * W;
@@ -366,6 +366,13 @@ int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int
     const bool bf2 = bf1;  // conv1 and conv2 of a block share shape and mode: both or neither
     if (bf2) { q.in_bf16 = a2_hi; q.in_bf16_lo = a2_lo; }
     if (cat_in) q.in2_bf16 = cat_in->raw;
+    if (pool_copies) {  // bf16 mode: the pooled output as blocked bf16 copies for the next encoder block
+        if (!bf2 || c->compute_mode != LASS_COMPUTE_BF16 || !pool_out || pool_h != 2)
+            return fail(c, LASS_ERR_STATE, "blocked bf16 pooled copies need the bf16 kernels and the fused 2x2 pool");
+        q.pool_out = nullptr;
+        q.pool_bf16 = pool_copies->raw; q.pool_bf16_act = pool_copies->act;
+        q.pool_act_scale = pool_copies->scale; q.pool_act_shift = pool_copies->shift; q.act_shift_bs = c->n_shift;
+    }
     if (act_out) {  // bf16 mode: the block output goes to the next transposed conv only - written as ONE blocked bf16
                     // tensor with that conv's BN+FiLM+leaky prologue already applied (in `out`'s storage)
         if (!bf2 || c->compute_mode != LASS_COMPUTE_BF16) return fail(c, LASS_ERR_STATE, "activated bf16 output needs the bf16 kernels");
@@ -899,6 +906,21 @@ int lass_separate(lass_ctx* c, const float* mixture, const float* condition, flo
         cb[d].scale = c->bn_scale + c->sites[rd.s1].off;
         cb[d].shift = shift + c->sites[rd.s1].off;
     }
+    // ... and encoder blocks 2-5 take their (pooled) input the same way, from the previous block's fused pool
+    CatCopies pc[4];
+    bool use_pc[4] = {false, false, false, false};
+    for (int i = 0; i < 4; ++i) {
+        const ResBlock& nx = c->enc[i + 1];
+        const long hwo = (long)pl.eh[i + 1] * pl.ew[i + 1];
+        use_pc[i] = c->fuse_catb && c->compute_mode == LASS_COMPUTE_BF16 && c->fuse_pool && kEnc[i].dh == 2 &&
+                    (pl.eh[i] % 2) == 0 && pl.ew[i] % 32 == 0 && (i != 0 || fuse_pre) && use_cb[5 - i] && use_cb[5 - (i + 1)] &&
+                    nx.cin != nx.cout && nx.cin % 16 == 0 && nx.b1 && nx.b2 && nx.bsc16;
+        pc[i].act = F(pl.pool[i]);
+        pc[i].raw = (char*)F(pl.pool[i]) + (size_t)B * nx.cin * hwo * 2;
+        pc[i].noct = nx.cin / 8;
+        pc[i].scale = c->bn_scale + c->sites[nx.s1].off;
+        pc[i].shift = shift + c->sites[nx.s1].off;
+    }
     // ---- encoder (resunet.py:556-562) -------------------------------------------------------------------------
     const float* x = F(pl.xpre);
     for (int i = 0; i < 7; ++i) {
@@ -919,7 +941,9 @@ int lass_separate(lass_ctx* c, const float* mixture, const float* condition, flo
         r = run_resblock(c, rb, x, rb.cin * HW, B, H, W, shift, F(pl.a2), o, o_bs, st,
                          fuse_pool ? F(pl.pool[i]) : nullptr, kEnc[i].dh,
                          (i == 0 && fuse_pre) ? F(pl.x0) : nullptr, nullptr,
-                         (i < 5 && use_cb[5 - i]) ? &cb[5 - i] : nullptr);
+                         (i < 5 && use_cb[5 - i]) ? &cb[5 - i] : nullptr,
+                         (i >= 1 && i <= 4 && use_pc[i - 1]) ? &pc[i - 1] : nullptr, nullptr,
+                         (i < 4 && use_pc[i]) ? &pc[i] : nullptr);
         if (r) return r;
         if (i < 6) {
             if (!fuse_pool) {

@@ -543,6 +543,8 @@ hipError_t lass_launch_conv_bf16(ConvKind kind, const ConvArgs& p, hipStream_t s
                     return launch_bf16<9, F_PHASEB | F_BIAS | F_INBF16 | F_IN2BF16 | F_EPIACT | F_OUTBF16 | F_NOSPLIT>(p, stream);
                 return launch_bf16<9, F_PHASEB | F_BIAS | F_INBF16 | F_EPIACT | F_OUTBF16 | F_NOSPLIT>(p, stream);
             }
+            if (p.in_bf16 && p.in2_bf16 && p.out_bf16)  // encoder block fed by, and feeding, blocked bf16 copies
+                return launch_bf16<9, F_PHASEB | F_BIAS | F_INBF16 | F_IN2BF16 | F_OUTBF16 | F_NOSPLIT>(p, stream);
             if (p.in_bf16 && p.in2_bf16) return launch_bf16<9, F_PHASEB | F_BIAS | F_INBF16 | F_IN2BF16 | F_NOSPLIT>(p, stream);
             if (p.in_bf16 && p.out_bf16) return launch_bf16<9, F_PHASEB | F_BIAS | F_INBF16 | F_OUTBF16 | F_NOSPLIT>(p, stream);
             if (p.in_bf16) return launch_bf16<9, F_PHASEB | F_BIAS | F_INBF16>(p, stream);

@@ -201,7 +201,7 @@ __device__ __forceinline__ void store_tile(const ConvArgs& p, f32x16 (&acc)[NCO]
                 for (int r = 0; r < 16; ++r) dst[(size_t)((r & 3) + 8 * (r >> 2)) * HW] = val[px][r];
             }
         }
-        if (p.pool_out) {  // wave-uniform
+        if (p.pool_out || p.pool_bf16) {  // wave-uniform
             const int Wo = p.W / 2;
             if (p.pool_h == 2) {
                 if (PW == 32 && NPX == 2) {
@@ -209,13 +209,38 @@ __device__ __forceinline__ void store_tile(const ConvArgs& p, f32x16 (&acc)[NCO]
                     const int Ho = p.H / 2;
                     float* dst = p.pool_out + ((size_t)b * p.N + n0 + co * 32 + 4 * khalf) * Ho * Wo +
                                  (size_t)(y >> 1) * Wo + (x >> 1);
+                    float pooled[16];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const float o0 = __shfl_xor(val[0][r], 1, 64), o1 = __shfl_xor(val[NPX - 1][r], 1, 64);
                         float sum = val[0][r] + o0;
                         sum += val[NPX - 1][r];
                         sum += o1;
-                        if (!(lane & 1) && y + 1 < p.H) dst[(size_t)((r & 3) + 8 * (r >> 2)) * Ho * Wo] = sum * 0.25f;
+                        pooled[r] = sum * 0.25f;
+                    }
+                    if (p.pool_bf16) {  // blocked bf16 copies for the next encoder block (raw + its conv1 prologue applied)
+                        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                        const size_t clipo = (size_t)b * (p.N / 8) * Ho * Wo;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const size_t unit = clipo + (size_t)((n0 + co * 32) / 8 + g) * Ho * Wo + (size_t)(y >> 1) * Wo + (x >> 1);
+                            bf16x4 raw, act;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const int n = n0 + co * 32 + 8 * g + 4 * khalf + i;
+                                raw[i] = (__bf16)pooled[4 * g + i];
+                                act[i] = (__bf16)leaky(pooled[4 * g + i] * p.pool_act_scale[n] +
+                                                       p.pool_act_shift[(size_t)b * p.act_shift_bs + n]);
+                            }
+                            if (!(lane & 1) && y + 1 < p.H) {
+                                *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(p.pool_bf16) + unit * 16 + khalf * 8) = raw;
+                                *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(p.pool_bf16_act) + unit * 16 + khalf * 8) = act;
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if (!(lane & 1) && y + 1 < p.H) dst[(size_t)((r & 3) + 8 * (r >> 2)) * Ho * Wo] = pooled[r];
                     }
                 }
             } else {

@@ -59,6 +59,12 @@ struct ConvArgs {
     int out_oct0 = 0;
     int out_noct = 0;                   // 0: N / 8
     const void* in2_bf16 = nullptr;     // phase B (1x1 shortcut) input as the blocked bf16 raw copy
+    // bf16 mode, encoder chain: the fused avg-pool output as two blocked bf16 copies (raw + activated with the NEXT block's
+    // conv1 prologue) instead of f32; replaces pool_out when set
+    void* pool_bf16 = nullptr;
+    void* pool_bf16_act = nullptr;
+    const float* pool_act_scale = nullptr;  // indexed by this launch's output channel
+    const float* pool_act_shift = nullptr;  // [B][act_shift_bs]
     const float* pre_w = nullptr;  // pre_conv (1x1, 1 -> 32) weight / bias for the *_PRE kinds
     const float* pre_b = nullptr;
     // fused output head (decoder_block6.conv2 only, N == 32, W == 512): after_conv (1x1, 32 -> 3, + bias) and the complex
