@@ -262,14 +262,16 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
     constexpr int LDS_U4 = HASB ? MaxU<PA_LDS, PB_LDS>::v : PA_LDS;
     constexpr int PH = PA::PH, WROWS = PA::WROWS, PHT = PA::PHT, NT = PA::NT;
     constexpr bool MASK = (FLAGS & F_MASK) != 0;
-    constexpr int NTAB = (EPI ? 2 * NT : 0) + (BIAS ? NT : 0) + (MASK ? 100 : 0);
+    constexpr bool OUTBF = (FLAGS & F_OUTBF16) != 0;
+    constexpr int NTAB = (EPI ? 2 * NT : 0) + (BIAS ? NT : 0) + (MASK ? 100 : 0) + (OUTBF ? 4 * NT : 0);
 
     __shared__ uint4 lds4[LDS_U4 + (NTAB + 3) / 4];
     float* tabs = reinterpret_cast<float*>(lds4 + LDS_U4);
     float* lds_es = tabs;
     float* lds_eh = tabs + NT;
     float* lds_bias = tabs + (EPI ? 2 * NT : 0);
-    float* lds_mw = tabs + NTAB - 100;  // MASK: after_conv weight [3][32] + bias [3]
+    float* lds_mw = tabs + (EPI ? 2 * NT : 0) + (BIAS ? NT : 0);  // MASK: after_conv weight [3][32] + bias [3]
+    float* lds_act = tabs + NTAB - 4 * NT;  // OUTBF: activation tables of the blocked copies (skip, pooled)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -298,6 +300,16 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
     }
     if (BIAS && tid < NT) lds_bias[tid] = p.bias[n0 + tid];
     if (MASK && tid < 99) lds_mw[tid] = tid < 96 ? p.mask_w[tid] : p.mask_b[tid - 96];
+    if (OUTBF && tid < NT) {
+        if (p.out_bf16_act) {
+            lds_act[tid] = p.act_scale[n0 + tid];
+            lds_act[NT + tid] = p.act_shift[(size_t)b * p.act_shift_bs + n0 + tid];
+        }
+        if (p.pool_bf16) {
+            lds_act[2 * NT + tid] = p.pool_act_scale[n0 + tid];
+            lds_act[3 * NT + tid] = p.pool_act_shift[(size_t)b * p.act_shift_bs + n0 + tid];
+        }
+    }
 
     PA pa;
     PB pb;
@@ -449,7 +461,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
         tconv_store<NCO, NPX, PW>(p, acc, b, n0, y0, x0, lane, wave);
     else
         store_tile<NCO, NPX, PW, FLAGS, RES_PF>(p, acc, rtmp, lds_es, lds_eh, b, n0, y0, x0, lane, wave,
-                                                 MASK ? lds_mw : nullptr);
+                                                 MASK ? lds_mw : nullptr, OUTBF ? lds_act : nullptr);
 }
 
 // dst[chunk][tap][octet][Cout][8] (bf16, RNE) = src[co][ci = chunk*16 + octet*8 + j][tap]   (taps = 9 or 1)

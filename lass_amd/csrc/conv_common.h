@@ -124,7 +124,8 @@ __device__ __forceinline__ void tconv_store(const ConvArgs& p, f32x16 (&acc)[NCO
 template <int NCO, int NPX, int PW, int FLAGS, bool HAVE_RTMP>
 __device__ __forceinline__ void store_tile(const ConvArgs& p, f32x16 (&acc)[NCO][NPX], const float (*rtmp)[16],
                                            const float* lds_es, const float* lds_eh, int b, int n0, int y0, int x0,
-                                           int lane, int wave, const float* lds_mw = nullptr) {
+                                           int lane, int wave, const float* lds_mw = nullptr,
+                                           const float* lds_act = nullptr) {  // [4][32*NCO]: skip act scale/shift, pool act scale/shift
     static_assert((FLAGS & F_MASK) == 0 || NCO == 1, "the fused output head needs all 32 channels in one wave");
     constexpr int PH = 32 / PW, WROWS = NPX * PH;
     constexpr bool EPI = (FLAGS & F_EPIACT) != 0;
@@ -184,8 +185,8 @@ __device__ __forceinline__ void store_tile(const ConvArgs& p, f32x16 (&acc)[NCO]
                             hi[i] = (__bf16)v;
                             lo[i] = (__bf16)(v - (float)hi[i]);
                             if (p.out_bf16_act) {
-                                const int n = n0 + co * 32 + 8 * g + 4 * khalf + i;
-                                ac[i] = (__bf16)leaky(v * p.act_scale[n] + p.act_shift[(size_t)b * p.act_shift_bs + n]);
+                                const int nl = co * 32 + 8 * g + 4 * khalf + i;
+                                ac[i] = (__bf16)leaky(v * lds_act[nl] + lds_act[32 * NCO + nl]);
                             }
                         }
                         *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(p.out_bf16) + unit * 16 + khalf * 8) = hi;
@@ -227,10 +228,9 @@ __device__ __forceinline__ void store_tile(const ConvArgs& p, f32x16 (&acc)[NCO]
                             bf16x4 raw, act;
 #pragma unroll
                             for (int i = 0; i < 4; ++i) {
-                                const int n = n0 + co * 32 + 8 * g + 4 * khalf + i;
+                                const int nl = co * 32 + 8 * g + 4 * khalf + i;
                                 raw[i] = (__bf16)pooled[4 * g + i];
-                                act[i] = (__bf16)leaky(pooled[4 * g + i] * p.pool_act_scale[n] +
-                                                       p.pool_act_shift[(size_t)b * p.act_shift_bs + n]);
+                                act[i] = (__bf16)leaky(pooled[4 * g + i] * lds_act[2 * 32 * NCO + nl] + lds_act[3 * 32 * NCO + nl]);
                             }
                             if (!(lane & 1) && y + 1 < p.H) {
                                 *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(p.pool_bf16) + unit * 16 + khalf * 8) = raw;
