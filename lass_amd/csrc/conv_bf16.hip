@@ -263,7 +263,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
     constexpr int PH = PA::PH, WROWS = PA::WROWS, PHT = PA::PHT, NT = PA::NT;
     constexpr bool MASK = (FLAGS & F_MASK) != 0;
     constexpr bool OUTBF = (FLAGS & F_OUTBF16) != 0;
-    constexpr int NTAB = (EPI ? 2 * NT : 0) + (BIAS ? NT : 0) + (MASK ? 100 : 0) + (OUTBF ? 4 * NT : 0);
+    constexpr bool TCV = (FLAGS & F_TCONV) != 0;
+    constexpr int NTAB = (EPI ? 2 * NT : 0) + (BIAS ? NT : 0) + (MASK ? 100 : 0) + (OUTBF ? 4 * NT : 0) + (TCV ? 16 * NCO : 0);
 
     __shared__ uint4 lds4[LDS_U4 + (NTAB + 3) / 4];
     float* tabs = reinterpret_cast<float*>(lds4 + LDS_U4);
@@ -271,7 +272,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
     float* lds_eh = tabs + NT;
     float* lds_bias = tabs + (EPI ? 2 * NT : 0);
     float* lds_mw = tabs + (EPI ? 2 * NT : 0) + (BIAS ? NT : 0);  // MASK: after_conv weight [3][32] + bias [3]
-    float* lds_act = tabs + NTAB - 4 * NT;  // OUTBF: activation tables of the blocked copies (skip, pooled)
+    float* lds_act = tabs + NTAB - 4 * NT - (TCV ? 16 * NCO : 0);  // OUTBF: activation tables of the blocked copies (skip, pooled)
+    float* lds_tact = tabs + NTAB - 16 * NCO;  // TCONV with blocked outputs: consumer prologue of this tile's 8*NCO channels
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -300,6 +302,10 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
     }
     if (BIAS && tid < NT) lds_bias[tid] = p.bias[n0 + tid];
     if (MASK && tid < 99) lds_mw[tid] = tid < 96 ? p.mask_w[tid] : p.mask_b[tid - 96];
+    if (TCV && p.out_bf16 && tid < 8 * NCO) {
+        lds_tact[tid] = p.act_scale[n0 / 4 + tid];
+        lds_tact[8 * NCO + tid] = p.act_shift[(size_t)b * p.act_shift_bs + n0 / 4 + tid];
+    }
     if (OUTBF && tid < NT) {
         if (p.out_bf16_act) {
             lds_act[tid] = p.act_scale[n0 + tid];
@@ -458,7 +464,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
         PB::compute(lds4, wl_b, acc, lane, wave);
     }
     if (FLAGS & F_TCONV)
-        tconv_store<NCO, NPX, PW>(p, acc, b, n0, y0, x0, lane, wave);
+        tconv_store<NCO, NPX, PW>(p, acc, b, n0, y0, x0, lane, wave, lds_tact);
     else
         store_tile<NCO, NPX, PW, FLAGS, RES_PF>(p, acc, rtmp, lds_es, lds_eh, b, n0, y0, x0, lane, wave,
                                                  MASK ? lds_mw : nullptr, OUTBF ? lds_act : nullptr);

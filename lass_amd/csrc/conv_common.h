@@ -52,7 +52,7 @@ __device__ __forceinline__ void mask_pixel(const ConvArgs& p, int b, int t, int 
 // so each lane writes 8 contiguous bytes and a half-wave a contiguous 256-B run of the up-sampled row.
 template <int NCO, int NPX, int PW>
 __device__ __forceinline__ void tconv_store(const ConvArgs& p, f32x16 (&acc)[NCO][NPX], int b, int n0, int y0, int x0,
-                                            int lane, int wave) {
+                                            int lane, int wave, const float* lds_tact = nullptr) {  // [2][8*NCO]
     constexpr int PH = 32 / PW, WROWS = NPX * PH;
     const int HW = p.H * p.W;
     const int khalf = lane >> 5, j = lane & 31;
@@ -92,8 +92,7 @@ __device__ __forceinline__ void tconv_store(const ConvArgs& p, f32x16 (&acc)[NCO
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
                         raw[k] = (__bf16)ch[bb][k];
-                        const int c = oct * 8 + k;
-                        act[k] = (__bf16)leaky(ch[bb][k] * p.act_scale[c] + p.act_shift[(size_t)b * p.act_shift_bs + c]);
+                        act[k] = (__bf16)leaky(ch[bb][k] * lds_tact[co * 8 + k] + lds_tact[8 * NCO + co * 8 + k]);
                     }
                     *reinterpret_cast<bf16x8*>(reinterpret_cast<char*>(p.out_bf16) + (unit + bb) * 16) = raw;
                     *reinterpret_cast<bf16x8*>(reinterpret_cast<char*>(p.out_bf16_act) + (unit + bb) * 16) = act;
