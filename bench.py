@@ -190,6 +190,8 @@ def main():
                          "executed_tflops": executed if args.dtype == "f32" else achieved,
                          "executed_frac": (executed if args.dtype == "f32" else achieved) / peak,
                          "hbm_algorithmic_gbs": hbm_gbs, "hbm_peak_gbs": PEAK_HBM_GBS, "hbm_frac": hbm_gbs / PEAK_HBM_GBS,
+                         "hbm_model": "compulsory bytes with f32 activation storage (SURVEY 8d); the bf16 mode keeps block "
+                                      "intermediates, decoder concats and pooled outputs as bf16, so it moves fewer bytes",
                          "launches_per_step": launches / args.steps, "avg_launch_ms": ms / max(1, launches),
                          "algorithmic_gflop_per_step": conv_flops / 1e9,
                          "whole_step_tflops": total_flops / (dt / args.steps) / 1e12},
