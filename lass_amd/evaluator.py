@@ -99,6 +99,7 @@ class DCASEEvaluator:
         with torch.no_grad(), ThreadPoolExecutor(max_workers=self.io_workers) as pool:
             # sliding window of decode jobs: at most two batches ahead of the one on the GPU
             pending = deque()
+            pending_stats = []
             nxt = lo
 
             def refill():
@@ -130,11 +131,12 @@ class DCASEEvaluator:
                 conditions = self._conditions(pl_model, captions, device)
                 input_dict = {"mixture": mix[:, None, :], "condition": conditions}
                 sep = pl_model.ss_model(input_dict)["waveform"][:, 0, :]
-                length = src.shape[1]
-                st_sep = eng.sdr_stats(src, sep.contiguous()).cpu().numpy()
-                st_mix = eng.sdr_stats(src, mix).cpu().numpy()
-                sdr, sisdr = stats_to_db(st_sep, length)
-                sdr_no_sep, _ = stats_to_db(st_mix, length)
+                # the (B,6) f64 statistics stay on the device: no host synchronisation inside the loop, so decoding /
+                # staging of the next batch overlaps this batch's kernels; they are fetched once after the loop
+                pending_stats.append((eng.sdr_stats(src, sep.contiguous()), eng.sdr_stats(src, mix), src.shape[1]))
+            for st_sep, st_mix, length in pending_stats:
+                sdr, sisdr = stats_to_db(st_sep.cpu().numpy(), length)
+                sdr_no_sep, _ = stats_to_db(st_mix.cpu().numpy(), length)
                 rows.append(np.stack([sdr, sdr - sdr_no_sep, sisdr], axis=1))
         local = np.concatenate(rows, axis=0) if rows else np.zeros((0, 3))
         allrows = ldist.gather_rows(local, n_total, device)
