@@ -570,12 +570,14 @@ hipError_t launch_one(const ConvArgs& p0, hipStream_t stream) {
     // faster; the single-buffered kernel (higher occupancy) everywhere else
     const bool db = var < 0 ? (TAPS == 9 && NCO == 2 && PW == 32 && nchunks >= 16 && !(FLAGS & F_RES))
                             : ((var & 1) != 0 && !(FLAGS & F_RES));
-    if (db) {
-        if constexpr (TAPS == 9 && NCO == 2 && PW == 32 && !(FLAGS & F_RES))
+    constexpr bool HAS_DB = TAPS == 9 && NCO == 2 && PW == 32 && !(FLAGS & F_RES);  // geometries the db kernel exists for
+    if constexpr (HAS_DB) {
+        if (db) {
             hipLaunchKernelGGL((conv_kernel_db<TAPS, NCO, NPX, PW, FLAGS>), grid, dim3(NTHREADS), 0, stream, p);
-    } else {
-        hipLaunchKernelGGL((conv_kernel_sb<TAPS, NCO, NPX, PW, FLAGS>), grid, dim3(NTHREADS), 0, stream, p);
+            return hipGetLastError();
+        }
     }
+    hipLaunchKernelGGL((conv_kernel_sb<TAPS, NCO, NPX, PW, FLAGS>), grid, dim3(NTHREADS), 0, stream, p);
     return hipGetLastError();
 }
 
