@@ -469,6 +469,22 @@ def test_bf16_mode_convblock_and_waveform(synthetic_sd, oracle_sd, monkeypatch):
     assert _relerr(out2, out) < 1e-5
 
 
+@pytest.mark.parametrize("mode", ["bf16", "bf16x3"])
+def test_bf16_modes_ragged_shapes(synthetic_sd, mode):
+    """Frame counts that leave odd heights at the bottom of the U-Net (T = 151 -> 160 -> H = 5 at encoder_block6) and a
+    batch of 3: the bf16 hand-over paths must track the f32 path (same weights, same inputs)."""
+    from lass_amd.resunet import ResUNet30
+    _, mix = synthetic.make_mixtures(3, 24000)
+    inp = {"mixture": torch.from_numpy(mix)[:, None, :].to(DEV), "condition": torch.from_numpy(synthetic.make_condition(3)).to(DEV)}
+    outs = {}
+    for m_ in ("f32", mode):
+        m = ResUNet30(1, 1, 512)
+        m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synthetic_sd.items()})
+        outs[m_] = m.to(DEV).eval().set_compute_dtype(m_)(inp)["waveform"].cpu()
+    rel = _relerr(outs[mode], outs["f32"])
+    assert rel < (5e-2 if mode == "bf16" else 1e-4), rel
+
+
 def test_bf16x3_split_mode_is_f32_accurate(synthetic_sd, oracle_sd, golden_dir):
     """LASS_COMPUTE_BF16X3: operands split hi+lo (two bf16), products hi*hi + hi*lo + lo*hi on the bf16 MFMA with f32
     accumulation.  ~16 mantissa bits per operand: must stay within the f32 path's own tolerance class (bar 1e-4)."""
