@@ -2,7 +2,6 @@
 to liblass_hip.  torch is plumbing here (device memory, streams); every number is produced by the HIP kernels."""
 from __future__ import annotations
 
-import ctypes
 from ctypes import byref, c_char_p, c_double, c_int, c_int64, c_size_t, c_void_p
 from typing import Dict, Optional
 

@@ -3,7 +3,6 @@
 CPU part: the oracle's per-window STFT is pinned to torch.stft for the reference's window set (config
 stft_win_lengths [256, 512, 2048], hop 160), and the file format / dataset reader round-trip is exercised with CPU
 tensors.  GPU part: lass_multi_stft (one launch for all windows) against the oracle."""
-import numpy as np
 import pytest
 import torch
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-layer timing of the residual blocks / transposed convs at the BASELINE configs[1] shapes (B=16, T=1024).
 Usage (GPU box): LASS_CONV_VARIANT=n python tools/conv_bench.py [--iters 5] [--only enc1,dec6]"""
-import argparse, os, sys, json
+import argparse, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lass_amd import arch, synthetic
