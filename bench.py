@@ -186,7 +186,7 @@ def main():
                          "algorithm": ("bf16 MFMA direct conv, f32 activations converted while staged"
                                        + (" (hi+lo split operands, 3 MFMAs per product)" if args.dtype == "bf16x3" else ""))
                                       if args.dtype != "f32" else
-                                      ("Winograd F(2x2,3x3) on f32 MFMA for W>=32, direct below" if wino else "direct"),
+                                      ("Winograd F(2x2,3x3) on the f32 MFMA (all 3x3 convs; 1x1 shortcuts in the transform domain)" if wino else "direct"),
                          "executed_tflops": executed if args.dtype == "f32" else achieved,
                          "executed_frac": (executed if args.dtype == "f32" else achieved) / peak,
                          "hbm_algorithmic_gbs": hbm_gbs, "hbm_peak_gbs": PEAK_HBM_GBS, "hbm_frac": hbm_gbs / PEAK_HBM_GBS,
