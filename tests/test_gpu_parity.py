@@ -298,6 +298,22 @@ def test_c_abi_error_paths(eng, synthetic_sd):
     assert torch.isfinite(eng.separate(mix, cond)).all()
 
 
+def test_random_shapes_against_oracle(model, oracle_sd):
+    """Seeded random (batch, length) pairs - lengths that are no multiple of the hop, frame counts that leave odd heights
+    down the U-Net, batch sizes that do not fill a tile - against the CPU oracle."""
+    from oracle import resunet as orr
+    rng = np.random.default_rng(2024)
+    for _ in range(6):
+        B = int(rng.integers(1, 5))
+        L = int(rng.integers(513, 30000))
+        x = torch.from_numpy((rng.standard_normal((B, 1, L)) * 0.1).astype(np.float32))
+        cond = torch.from_numpy(synthetic.make_condition(B))
+        out = model({"mixture": x.to(DEV), "condition": cond.to(DEV)})["waveform"].cpu()
+        ref = orr.forward(oracle_sd, {"mixture": x, "condition": cond})["waveform"]
+        assert out.shape == ref.shape == (B, 1, L)
+        assert _rms(out - ref) < 1e-5 * max(_rms(ref), 1e-3) + 2e-6, (B, L)
+
+
 def test_long_form_clip_config5(model, oracle_sd):
     """BASELINE configs[4] input shape: one 30 s clip at 32 kHz (L = 960000, T = 6001 -> 6016) through the same
     single-STFT trunk (the reference's multi-STFT model is not runnable).  Whole-clip forward vs the oracle."""
