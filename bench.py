@@ -1,31 +1,103 @@
 #!/usr/bin/env python3
 """Benchmark of the separation hot path (BASELINE.json metric: clips/sec, one clip = 10 s @ 16 kHz).
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N = 1 runs in this process.  N > 1 without WORLD_SIZE in the environment: this process touches no GPU, builds the
+library in a child, starts N fresh ranks (`python -m torch.distributed.run --nproc-per-node N bench.py ...`, one rank
+per GPU, backend "nccl" = RCCL), forwards rank 0's JSON line and exits with the launcher's code.  Launched under
+torch.distributed.run directly (WORLD_SIZE set) it is one of those ranks.
 
 A "step" is one pass of the hot path - lass_separate: STFT -> FiLM ResUNet30 -> mask -> iSTFT - over one batch of
 synthetic mixtures already resident in HBM.  Workload at N=1 = BASELINE.json configs[1]: ResUNet30 fp32, batch 16,
 10 s @ 16 kHz, fixed (precomputed) condition embeddings, seeded random-init weights.  For N>1 every rank separates its
-own 16 clips (weak scaling; clip-level sharding, no data-path collective); value = clips of all ranks / max-over-ranks
-time.  Prints ONE JSON line on rank 0.
+own 16 clips (weak scaling; clip-level sharding, no data-path collective: configs[3] at N=8); after the timed loop each
+rank reduces its clips to SDR / SDRi / SI-SDR rows on the device and ONE all-gather of those rows ends the
+job.  value = clips of all ranks / max-over-ranks time.  Prints ONE JSON line on rank 0.
+
+Timing protocol: `value` comes from an un-instrumented loop; the per-kernel-class milliseconds (roofline) come from a
+second, shorter loop with HIP events around every class on the launch stream (lass_set_profiling).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2, 64 FLOP/clk/SIMD @ 2.4 GHz
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
+WINO_MULT_REDUCTION = 9.0 / 4.0  # F(2x2,3x3): 16 multiplies per 2x2 output tile and (cin,cout) instead of 36
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="clips per GPU per step (BASELINE configs[1]: 16)")
+    ap.add_argument("--length", type=int, default=160000, help="samples per clip (10 s @ 16 kHz)")
+    ap.add_argument("--dtype", choices=["f32", "bf16", "bf16x3"], default="f32",
+                    help="headline arithmetic: f32 = BASELINE configs[1]; bf16 = configs[2] (bf16-MFMA convolutions)")
+    ap.add_argument("--modes", default="auto",
+                    help="extra compute modes timed after the headline region and reported under `modes` "
+                         "(comma list of bf16,bf16x3; 'auto' = both at N=1 with --dtype f32, 'none' = skip)")
+    ap.add_argument("--profile-steps", type=int, default=5, help="steps of the second, HIP-event-instrumented loop")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend of the one exchange step; gloo also lets ranks share a GPU "
+                         "(rehearsal on a 1-GPU box)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-full", action="store_true",
+                    help="SURVEY 8(d) protocol in full at B=16 as well (3 warm-up + 10 timed; minutes of CPU time)")
+    ap.add_argument("--print-launch", action="store_true", help="N>1 parent: print the launch command and exit")
+    return ap.parse_args(argv)
+
+
+# ---- N > 1 parent: never touches the GPU ------------------------------------------------------------------------------
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_command(argv, nproc: int, port: int):
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py")] + list(argv)
+
+
+def parent_launch(args, argv) -> int:
+    """Spawn the ranks as fresh children (a GPU-initialised process must never exec or fork into ranks)."""
+    cmd = launch_command(argv, args.gpus, free_port())
+    if args.print_launch:
+        print(json.dumps({"launch": cmd}))
+        return 0
+    # build once, in a child, so the ranks find an up-to-date library (they re-check under a file lock)
+    subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build()"], cwd=ROOT, check=True,
+                   stdout=sys.stderr)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in p.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    if p.returncode == 0 and line is None:
+        print("bench.py: the ranks printed no result line", file=sys.stderr)
+        return 1
+    return p.returncode
+
+
+# ---- helpers of a rank ---------------------------------------------------------------------------------------------------
 def host_cores() -> int:
     """CPU threads this process may actually use: affinity mask, capped by the cgroup CPU quota; a GPU box exposes all
     of the host's logical CPUs but grants a 16-core share per GPU, and over-subscribing it makes the baseline
@@ -43,164 +115,284 @@ def host_cores() -> int:
     return min(n, 16)
 
 
-def pmc_traffic():
-    """HBM bytes per conv3x3 launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
-    command (profiles/rNN/conv_traffic.json, made by tools/traffic_summary.py); bench.py itself cannot read PMCs."""
+def cpu_model() -> str:
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def pmc_traffic(dtype: str):
+    """HBM bytes per launch of the dominant kernel class from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+    passes of this same command (profiles/rNN/conv_traffic_<dtype>.json, made by tools/traffic_summary.py with the
+    FETCH_SIZE calibration of tools/fetch_calib): bench.py itself cannot read PMCs, so this is a committed measurement
+    of this workload, labelled as such."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "conv_traffic.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"conv_traffic_{dtype}.json")))
     if not files:
-        return None, None
+        return None
     d = json.load(open(files[-1]))
-    return d.get("traffic_bytes_per_launch"), {"source": os.path.relpath(files[-1], ROOT),
-                                               "raw_bytes_per_launch": d.get("traffic_bytes_per_launch_raw"),
-                                               "note": d.get("note")}
+    d["source"] = "committed profile " + os.path.relpath(files[-1], ROOT)
+    return d
 
 
-def cpu_baseline(sd, length, seconds_budget=20.0):
-    """The oracle (CPU restatement of the reference path) timed on this box's host cores: a bounded sample of the same
-    workload (batch-1 forwards of 10 s clips until ~seconds_budget of CPU time is spent)."""
+def cpu_baseline(sd, length, full=False):
+    """The oracle (CPU restatement of the reference path, kind "port") timed on this box's host cores, SURVEY 8(d)
+    protocol: B=1 with 3 warm-up + 10 timed forwards, median; B=16 the same when --cpu-full, else ONE warm forward
+    (a B=16 forward takes ~15-20 s of CPU time, the default bench must finish within minutes)."""
+    import numpy as np
+    import torch
     from lass_amd import synthetic
     from oracle import resunet as orr
     cores = host_cores()
     torch.set_num_threads(cores)
     osd = orr.to_torch(sd)
-    _, mix = synthetic.make_mixtures(1, length)
-    inp = {"mixture": torch.from_numpy(mix)[:, None, :], "condition": torch.from_numpy(synthetic.make_condition(1))}
-    orr.forward(osd, inp)  # warm-up
-    n, t0 = 0, time.perf_counter()
-    while True:
-        orr.forward(osd, inp)
-        n += 1
-        dt = time.perf_counter() - t0
-        if dt >= seconds_budget or n >= 50:
-            break
-    return {"value": n / dt, "unit": "clips/s", "cores": cores, "kind": "port",
-            "sample": f"{n} batch-1 forwards of one {length / 16000:.0f} s clip, oracle/resunet.py (torch-CPU fp32), "
-                      f"{torch.get_num_threads()} threads"}
+
+    def run(batch, warm, timed):
+        _, mix = synthetic.make_mixtures(min(batch, 2), length)
+        mix = np.concatenate([mix] * ((batch + 1) // 2))[:batch]
+        inp = {"mixture": torch.from_numpy(mix)[:, None, :],
+               "condition": torch.from_numpy(synthetic.make_condition(batch))}
+        for _ in range(warm):
+            orr.forward(osd, inp)
+        ts = []
+        for _ in range(timed):
+            t0 = time.perf_counter()
+            orr.forward(osd, inp)
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts)), ts
+
+    t1, ts1 = run(1, 3, 10)
+    w16, n16 = (3, 10) if full else (0, 1)
+    t16, ts16 = run(16, w16, n16)
+    return {"value": 1.0 / t1, "unit": "clips/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+            "batch16_value": 16.0 / t16,
+            "sample": f"oracle/resunet.py (torch-CPU fp32, FFT-based STFT) on {length / 16000:.0f} s clips, "
+                      f"{torch.get_num_threads()} threads: B=1 3 warm-up + 10 timed forwards, median {t1:.3f} s "
+                      f"(min {min(ts1):.3f}, max {max(ts1):.3f}); B=16 {w16} warm-up + {n16} timed, median {t16:.2f} s"}
+
+
+def conv_flops(rows, B, wino):
+    """(algorithmic, executed) FLOPs per step of the conv3x3_mfma class (3x3 convs + the 1x1 shortcuts fused into them).
+    Executed: a Winograd F(2x2,3x3) launch performs 16 instead of 36 multiplies per 2x2 tile and (cin, cout) - 4/9 of
+    the direct count; the transform-domain shortcut performs 4 per tile = the direct 1x1 count."""
+    alg = exe = 0.0
+    for r in rows:
+        if r["kind"] == "3x3":
+            alg += 2.0 * B * r["macs"]
+            exe += 2.0 * B * r["macs"] * ((4.0 / 9.0) if (wino and r["h"] % 2 == 0) else 1.0)
+        elif r["name"].endswith(".shortcut"):
+            alg += 2.0 * B * r["macs"]
+            exe += 2.0 * B * r["macs"]
+    return alg, exe
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=16, help="clips per GPU per step (BASELINE configs[1]: 16)")
-    ap.add_argument("--length", type=int, default=160000, help="samples per clip (10 s @ 16 kHz)")
-    ap.add_argument("--dtype", choices=["f32", "bf16", "bf16x3"], default="f32",
-                    help="f32 = BASELINE configs[1] (headline); bf16 = configs[2] (bf16-MFMA convolutions)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0)
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(parent_launch(args, sys.argv[1:]))
 
+    launched = "WORLD_SIZE" in os.environ
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    import numpy as np
+    import torch
+    import torch.distributed as dist
     import __graft_entry__ as ge
     ge.build()
     from lass_amd import arch, synthetic
+    from lass_amd import dist as ldist
+    from lass_amd.metrics import stats_to_db
     from lass_amd.resunet import ResUNet30
 
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % ndev if args.backend == "gloo" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    # The exchange step runs on a real process group at every N: under the launcher its rendezvous comes from the
+    # environment; a plain N=1 run makes a single-rank group so the RCCL path executes there too.
+    pg_error = None
+    try:
+        if launched:
+            dist.init_process_group(args.backend, **({"device_id": dev} if args.backend == "nccl" else {}))
+        else:
+            dist.init_process_group(args.backend, init_method=f"tcp://127.0.0.1:{free_port()}", rank=0, world_size=1,
+                                    **({"device_id": dev} if args.backend == "nccl" else {}))
+    except Exception as e:  # a single-GPU run still reports its throughput; N>1 cannot continue
+        if world > 1:
+            raise
+        pg_error = f"{type(e).__name__}: {e}"
 
     sd = synthetic.make_state_dict()
     model = ResUNet30(1, 1, 512)
     model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
     model = model.to(dev).eval().set_compute_dtype(args.dtype)
-    eng = model.engine
     B, L = args.batch, args.length
     # distinct synthetic clips per rank; a small pool tiled to B keeps host-side generation short
     pool = min(B, 4)
-    _, mix = synthetic.make_mixtures(pool, L, first=rank * pool)
-    mix = np.concatenate([mix] * ((B + pool - 1) // pool))[:B]
-    mixture = torch.from_numpy(mix).to(dev)
+    src_np, mix_np = synthetic.make_mixtures(pool, L, first=rank * pool)
+    tile = lambda a: np.concatenate([a] * ((B + pool - 1) // pool))[:B]  # noqa: E731
+    source = torch.from_numpy(tile(src_np)).to(dev)
+    mixture = torch.from_numpy(tile(mix_np)).to(dev)
     cond = torch.from_numpy(synthetic.make_condition(B)).to(dev)
     out = torch.empty_like(mixture)
 
     def barrier():
-        if world > 1:
+        if dist.is_initialized() and world > 1:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        eng.separate(mixture, cond, out)
-    torch.cuda.synchronize()
-    eng.set_profiling(True)   # HIP events around every kernel class, on the launch stream, inside the timed region
-    eng.profile(reset=True)
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.separate(mixture, cond, out)
-    torch.cuda.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
-    prof = eng.profile(reset=True)
-    eng.set_profiling(False)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def timed(eng, steps, warmup):
+        """W untimed steps, then exactly `steps` bracketed by barrier + synchronize; max over ranks."""
+        for _ in range(warmup):
+            eng.separate(mixture, cond, out)
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.separate(mixture, cond, out)
+        torch.cuda.synchronize()
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist.is_initialized() and world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    def profiled(eng, steps):
+        """Second loop with HIP events around every kernel class (on the launch stream) -> {class: (ms, launches)}."""
+        eng.set_profiling(True)
+        eng.profile(reset=True)
+        for _ in range(steps):
+            eng.separate(mixture, cond, out)
+            torch.cuda.synchronize()
+            eng.profile(reset=False)  # folds this step's events so the pre-sized pool is reused
+        prof = eng.profile(reset=True)
+        eng.set_profiling(False)
+        return prof
+
+    eng = model.engine
+    dt = timed(eng, args.steps, args.warmup)
     assert torch.isfinite(out).all()
 
+    # ---- the one exchange step (SURVEY 8e): per-clip metric rows, all-gathered over the process group ---------------
+    exch = {"rccl_ranks": 0, "allgather_ms": None, "backend": args.backend}
+    if pg_error is None:
+        st_sep = eng.sdr_stats(source, out).cpu().numpy()
+        st_mix = eng.sdr_stats(source, mixture).cpu().numpy()
+        sdr, sisdr = stats_to_db(st_sep, L)
+        sdr0, _ = stats_to_db(st_mix, L)
+        rows_local = np.stack([sdr, sdr - sdr0, sisdr], axis=1)
+        ldist.gather_rows(rows_local, world * B, dev)  # first call sets the communicator up
+        torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        allrows = ldist.gather_rows(rows_local, world * B, dev)
+        torch.cuda.synchronize()
+        exch.update(rccl_ranks=dist.get_world_size() if args.backend == "nccl" else 0, ranks=dist.get_world_size(),
+                    allgather_ms=(time.perf_counter() - t0) * 1e3, rows=int(allrows.shape[0]),
+                    mean_sdr=float(allrows[:, 0].mean()), mean_sdri=float(allrows[:, 1].mean()),
+                    mean_sisdr=float(allrows[:, 2].mean()))
+        assert allrows.shape == (world * B, 3) and np.isfinite(allrows).all()
+        assert np.array_equal(allrows[rank * B:(rank + 1) * B], rows_local)
+    else:
+        exch["error"] = pg_error
+
+    psteps = max(1, min(args.profile_steps, args.steps))
+    prof = profiled(eng, psteps)
+
+    rows = arch.conv_layer_table(arch.padded_frames(arch.frames_for(L)))
+    wino = os.environ.get("LASS_WINO", "1") != "0"
+
+    def mode_record(dtype, dt_mode, steps, prof_mode):
+        """Roofline numbers of one compute mode from its timed and profiled loops."""
+        alg, exe_f32 = conv_flops(rows, B, wino)
+        ms, launches = prof_mode["conv3x3_mfma"]
+        per_step = ms / psteps * 1e-3
+        if dtype == "f32":
+            exe, peak = exe_f32, PEAK_F32_MFMA_TFLOPS
+        else:  # direct bf16 MFMA convolution; the split mode issues three MFMAs per product
+            exe, peak = alg * (3.0 if dtype == "bf16x3" else 1.0), PEAK_BF16_MFMA_TFLOPS
+        byt = float(B) * arch.conv3x3_bytes_per_clip(L, 2 if dtype == "bf16" else 4)
+        return {"clips_s": world * B * steps / dt_mode, "ms_per_step": dt_mode / steps * 1e3,
+                "conv_ms": per_step * 1e3, "launches_per_step": launches / psteps,
+                "avg_launch_ms": ms / max(1, launches),
+                "executed_tflops": exe / per_step / 1e12, "algorithmic_tflops": alg / per_step / 1e12,
+                "peak_tflops": peak, "frac": exe / per_step / 1e12 / peak,
+                "hbm_algorithmic_gbs": byt / per_step / 1e9, "hbm_frac": byt / per_step / 1e9 / PEAK_HBM_GBS,
+                "hbm_model": ("blocked bf16 activation storage between conv launches (2 B/element)" if dtype == "bf16"
+                              else "f32 activation storage (4 B/element)") + ", ideal per-launch fusion (SURVEY 8d)",
+                "kernel_ms_per_step": {k: v[0] / psteps for k, v in prof_mode.items()}}
+
+    head = mode_record(args.dtype, dt, args.steps, prof)
+
+    modes = {}
+    want = args.modes
+    if want == "auto":
+        want = "bf16,bf16x3" if (world == 1 and args.dtype == "f32") else "none"
+    for m in [x for x in want.split(",") if x and x != "none"]:
+        model.set_compute_dtype(m)
+        e2 = model.engine
+        dt_m = timed(e2, args.steps, 2)
+        assert torch.isfinite(out).all()
+        modes[m] = mode_record(m, dt_m, args.steps, profiled(e2, psteps))
+    if modes:
+        model.set_compute_dtype(args.dtype)
+
     if rank == 0:
-        rows = arch.conv_layer_table(arch.padded_frames(arch.frames_for(L)))
-        conv_flops = 2.0 * B * sum(r["macs"] for r in rows if r["kind"] == "3x3" or r["name"].endswith(".shortcut"))
+        alg_step, _ = conv_flops(rows, B, wino)
         total_flops = 2.0 * B * sum(r["macs"] for r in rows)
-        ms, launches = prof["conv3x3_mfma"]
-        per_step_ms = ms / args.steps
-        achieved = conv_flops / (per_step_ms * 1e-3) / 1e12 if per_step_ms > 0 else 0.0
-        traffic, traffic_meta = pmc_traffic() if (B, L) == (16, 160000) else (None, None)
-        # With the Winograd kernels (default) the 3x3 convs (even H) execute 4 instead of 9 multiplies per output and
-        # (cin, cout): `achieved` stays the ALGORITHMIC (direct-convolution) rate and may exceed the MFMA peak; the
-        # rate the matrix pipe really sustains is `executed_tflops`.
-        wino = os.environ.get("LASS_WINO", "1") != "0"
-        exec_flops = 0.0
-        for r in rows:
-            if r["kind"] == "3x3":
-                exec_flops += 2.0 * B * r["macs"] * ((4.0 / 9.0) if (wino and r["h"] % 2 == 0) else 1.0)
-            elif r["name"].endswith(".shortcut"):  # transform-domain 1x1: 4 of 16 xi per 2x2 tile = direct-1x1 count
-                exec_flops += 2.0 * B * r["macs"]
-        executed = exec_flops / (per_step_ms * 1e-3) / 1e12 if per_step_ms > 0 else 0.0
-        peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
-        conv_bytes = float(B) * arch.conv3x3_bytes_per_clip(L)
-        hbm_gbs = conv_bytes / (per_step_ms * 1e-3) / 1e9 if per_step_ms > 0 else 0.0
+        traffic = pmc_traffic(args.dtype) if (B, L) == (16, 160000) else None
+        alg_bytes_launch = float(B) * arch.conv3x3_bytes_per_clip(L, 2 if args.dtype == "bf16" else 4) / max(1.0, head["launches_per_step"])
+        kernel = {"f32": "wino_kernel<...> x26: 3x3 convs as Winograd F(2x2,3x3) on v_mfma_f32_16x16x4_f32 + fused 1x1 "
+                         "shortcuts (conv3x3_mfma class)" if wino else "conv_kernel (direct f32 MFMA)",
+                  "bf16": "conv_bf16_kernel x26: direct 3x3 + fused 1x1 shortcuts on v_mfma_f32_32x32x16_bf16",
+                  "bf16x3": "conv_bf16_kernel (split operands, 3 MFMAs per product) x26"}[args.dtype]
         res = {
             "metric": "clips/sec (10s@16kHz)", "value": world * B * args.steps / dt, "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"ResUNet30 separate() {'fp32' if args.dtype == 'f32' else 'bf16-MFMA convs (f32 storage/accumulate)'}, "
+            "config": {"workload": f"ResUNet30 separate() {'fp32' if args.dtype == 'f32' else args.dtype + ' MFMA convolutions'}, "
                                    f"batch={B}/GPU, {L / 16000:.0f}s@16kHz clips, fixed precomputed condition embedding, "
-                                   f"seeded random-init weights (BASELINE configs[{1 if args.dtype == 'f32' else 2}])",
+                                   f"seeded random-init weights (BASELINE configs[{1 if args.dtype == 'f32' else 2}]"
+                                   f"{'; configs[3] sharding' if world > 1 else ''})",
                        "clips_per_gpu_per_step": B, "samples_per_clip": L, "parallelism": f"clip-sharded x{world}"},
             "realtime_factor": world * B * args.steps / dt * (L / 16000.0),
-            "roofline": {"bound": "mfma", "kernel": "conv3x3_mfma (3x3 convs + fused 1x1 shortcuts, f32 MFMA; achieved = algorithmic direct-conv FLOPs)",
-                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": traffic if args.dtype == "f32" else None,
-                         "traffic_meta": traffic_meta,
-                         "algorithm": ("bf16 MFMA direct conv, f32 activations converted while staged"
-                                       + (" (hi+lo split operands, 3 MFMAs per product)" if args.dtype == "bf16x3" else ""))
-                                      if args.dtype != "f32" else
-                                      ("Winograd F(2x2,3x3) on the f32 MFMA (all 3x3 convs; 1x1 shortcuts in the transform domain)" if wino else "direct"),
-                         "executed_tflops": executed if args.dtype == "f32" else achieved,
-                         "executed_frac": (executed if args.dtype == "f32" else achieved) / peak,
-                         "hbm_algorithmic_gbs": hbm_gbs, "hbm_peak_gbs": PEAK_HBM_GBS, "hbm_frac": hbm_gbs / PEAK_HBM_GBS,
-                         "hbm_model": "compulsory bytes with f32 activation storage (SURVEY 8d); the bf16 mode keeps block "
-                                      "intermediates, decoder concats and pooled outputs as bf16, so it moves fewer bytes",
-                         "launches_per_step": launches / args.steps, "avg_launch_ms": ms / max(1, launches),
-                         "algorithmic_gflop_per_step": conv_flops / 1e9,
+            "exchange": exch,
+            "roofline": {"bound": "mfma", "kernel": kernel,
+                         "achieved": head["executed_tflops"], "peak": head["peak_tflops"], "unit": "TFLOP/s",
+                         "frac": head["frac"],
+                         "achieved_is": "EXECUTED MFMA FLOPs of the class per step / its HIP-event time per step "
+                                        "(profiled loop); the algorithmic direct-conv rate is algorithmic_tflops",
+                         "algorithmic_tflops": head["algorithmic_tflops"],
+                         "winograd_mult_reduction": WINO_MULT_REDUCTION if (args.dtype == "f32" and wino) else 1.0,
+                         "algorithmic_gflop_per_step": alg_step / 1e9,
+                         "traffic": traffic["traffic_bytes_per_launch"] if traffic else None,
+                         "traffic_over_algorithmic": (traffic["traffic_bytes_per_launch"] / alg_bytes_launch) if traffic else None,
+                         "traffic_source": traffic["source"] if traffic else None,
+                         "traffic_fetch_calibration": traffic.get("fetch_calibration") if traffic else None,
+                         "algorithmic_bytes_per_launch": alg_bytes_launch,
+                         "launches_per_step": head["launches_per_step"], "avg_launch_ms": head["avg_launch_ms"],
+                         "class_ms_per_step": head["conv_ms"], "profiled_steps": psteps,
+                         "hbm_algorithmic_gbs": head["hbm_algorithmic_gbs"], "hbm_peak_gbs": PEAK_HBM_GBS,
+                         "hbm_frac": head["hbm_frac"], "hbm_model": head["hbm_model"],
                          "whole_step_tflops": total_flops / (dt / args.steps) / 1e12},
-            "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
+            "kernel_ms_per_step": head["kernel_ms_per_step"],
         }
+        if modes:
+            res["modes"] = modes
         if world == 1 and not args.no_cpu_baseline and args.dtype == "f32":
-            res["cpu_baseline"] = cpu_baseline(sd, L, args.cpu_seconds)
+            res["cpu_baseline"] = cpu_baseline(sd, L, args.cpu_full)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

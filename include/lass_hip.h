@@ -15,7 +15,8 @@
  *   - kernels are enqueued on the caller's `stream` (a hipStream_t passed as void*) and never synchronise.
  *   - the caller owns inputs, outputs and the workspace; the context owns re-laid-out weights and constant tables.
  *     `lass_separate` allocates nothing.
- *   - one context per (process, device); not re-entrant per context.
+ *   - one context per (process, device); not re-entrant per context.  Every entry point makes the context's device
+ *     current (hipSetDevice) before it launches or allocates, so the caller's current device does not matter.
  *   - there is NO CPU fallback: without a gfx950 device `lass_create` fails.
  */
 #ifndef LASS_HIP_H
@@ -42,11 +43,15 @@ typedef struct lass_ctx lass_ctx;
 #define LASS_I64 1
 
 /* compute modes for lass_finalize */
-#define LASS_COMPUTE_F32 0     /* f32 storage, f32 MFMA contractions (plain f32 FMAs; Winograd F(2x2,3x3) for W >= 32) */
-#define LASS_COMPUTE_BF16 1    /* f32 storage, 3x3 convs at W >= 32 contracted on the bf16 MFMA (operands rounded to bf16,
-                                  f32 accumulate): BASELINE configs[2]; reduced precision, looser parity */
+#define LASS_COMPUTE_F32 0     /* f32 storage, f32 MFMA contractions (plain f32 FMAs; Winograd F(2x2,3x3) for even H) */
+#define LASS_COMPUTE_BF16 1    /* convolutions contracted on the bf16 MFMA (operands rounded to bf16, f32 accumulate):
+                                  BASELINE configs[2].  Inside the workspace the tensors handed from one conv launch to
+                                  the next (block intermediates, decoder concats, pooled encoder outputs, transposed-conv
+                                  inputs) are stored as blocked bf16 [C/8][H][W][8]; spectra, masks and waveforms stay
+                                  f32.  Reduced precision, looser parity. */
 #define LASS_COMPUTE_BF16X3 2  /* as BF16 but every operand is split hi+lo (two bf16) and each product formed as
-                                  hi*hi + hi*lo + lo*hi on the bf16 MFMA: ~16 mantissa bits per operand */
+                                  hi*hi + hi*lo + lo*hi on the bf16 MFMA: ~16 mantissa bits per operand.  Block
+                                  intermediates are two blocked bf16 planes (hi, lo); everything else stays f32. */
 
 /* Library / ABI version (major*10000 + minor*100 + patch). */
 int lass_version(void);
@@ -72,7 +77,10 @@ int lass_set_param(lass_ctx* ctx, const char* name, const void* data, const int6
  * Must be called again after any lass_set_param. */
 int lass_finalize(lass_ctx* ctx, int compute_mode);
 
-/* Bytes of workspace `lass_separate` needs for B clips of L samples. */
+/* Bytes of workspace `lass_separate` needs for B clips of L samples.
+ * Limits: B >= 1 and 512 < L <= 2 616 319 (the kernels address one clip's tensors with 32-bit byte offsets; the largest,
+ * decoder_block6's concat, reaches 2^31 bytes there - 163 s at 16 kHz).  Longer clips are an LASS_ERR_ARG here and in
+ * lass_separate; the reference's own long-form route, chunk_inference (resunet.py:655-714), stays available. */
 int lass_workspace_bytes(const lass_ctx* ctx, int B, int L, size_t* bytes);
 
 /* The hot path.  mixture (B,L) f32, condition (B,512) f32 -> out (B,L) f32.
@@ -120,6 +128,28 @@ int lass_film_raw(lass_ctx* ctx, const float* condition, int B, float* film, voi
 int lass_convblock(lass_ctx* ctx, const char* prefix, const float* x, int B, int H, int W, const float* shift,
                    float* y, float* scratch, void* stream);
 
+/* One encoder block (resunet.py:186-198) by module name, e.g. "base.encoder_block3": the ConvBlockRes above plus
+ * F.avg_pool2d with the block's downsample ((2,2); (1,2) for encoder_block6) - fused into conv2's epilogue exactly as
+ * lass_separate does it (its own kernel when H is not divisible).  x (B,Cin,H,W) -> y (B,Cout,H,W) and
+ * pool (B,Cout,H/dh,W/2).  "base.conv_block7a" (downsample (1,1) = identity) takes pool == NULL. */
+int lass_encoder_block(lass_ctx* ctx, const char* name, const float* x, int B, int H, int W, const float* shift, float* y,
+                       float* pool, float* scratch, void* stream);
+
+/* STFT + magnitude/phase + the network-input prologue of ResUNet30_Base.forward (resunet.py:533-552): bn0 over
+ * frequency, zero-padding of T to a multiple of 32 AFTER bn0, last bin dropped.  wav (B,L) -> x0 (B,Tpad,512) and,
+ * where non-NULL, mag/cos/sin (B,T,513).  pre_conv (:555) is applied inside encoder_block1's staging. */
+int lass_front_end(lass_ctx* ctx, const float* wav, int B, int L, float* mag, float* cos_out, float* sin_out, float* x0,
+                   void* stream);
+
+/* Where lass_separate(B, L) leaves a named intermediate inside the caller's workspace (f32 compute mode; in the bf16
+ * modes several of these hold blocked bf16 data instead): byte offset, shape (B,C,H,W) and element strides.  Names:
+ * "mag" "cos" "sin" "x0" "out_real" "out_imag", "encoder_blockN" (the skip, stored in place inside the decoder's concat
+ * buffer), "encoder_blockN.pool", "conv_block7a", "decoder_blockN.up" (transposed-conv half of the concat),
+ * "decoder_blockN" (N = 6 is consumed by the fused output head and never written).  For parity tests of the fused
+ * stages against the reference's own taps.  Returns LASS_ERR_ARG for an unknown name. */
+int lass_workspace_tensor(const lass_ctx* ctx, int B, int L, const char* name, size_t* offset, int64_t shape[4],
+                          int64_t strides[4]);
+
 /* Transposed conv of a decoder block (resunet.py:254-255): x (B,Cin,h,w) -> y (B,Cout,h*sh,w*sw), with the
  * bn1 + FiLM + leaky-ReLU prologue.  name: "base.decoder_blockN". */
 int lass_upconv(lass_ctx* ctx, const char* name, const float* x, int B, int h, int w, const float* shift, float* y,
@@ -145,7 +175,9 @@ int lass_mix_at_snr(lass_ctx* ctx, float* source, const float* noise, const floa
 
 /* ---- instrumentation ---------------------------------------------------------------------------------------- */
 
-/* When enabled, lass_separate brackets each kernel class with HIP events on `stream` (costs a few us per launch). */
+/* When enabled, lass_separate brackets each kernel class with HIP events on `stream` (costs a few us per launch).
+ * The event pool (512 pairs, ~12 separations) is created HERE, never inside lass_separate; scopes beyond the pool are
+ * not timed, so read (lass_profile_get) or reset at least every few separations while profiling. */
 int lass_set_profiling(lass_ctx* ctx, int enabled);
 /* After a profiled lass_separate has completed (caller synchronised the stream): number of kernel classes, and for
  * class i its name, accumulated milliseconds and launch count since the last lass_profile_reset. */

@@ -32,6 +32,11 @@ SYMBOLS = [
     ("lass_film_raw", c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     ("lass_convblock", c_int, [c_void_p, c_char_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                c_void_p]),
+    ("lass_encoder_block", c_int, [c_void_p, c_char_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_void_p]),
+    ("lass_front_end", c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    ("lass_workspace_tensor", c_int, [c_void_p, c_int, c_int, c_char_p, POINTER(c_size_t), POINTER(c_int64),
+                                      POINTER(c_int64)]),
     ("lass_upconv", c_int, [c_void_p, c_char_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     ("lass_mask_apply", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
                                 c_void_p, c_void_p]),

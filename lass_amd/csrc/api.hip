@@ -252,6 +252,11 @@ enum ProfClass { P_STFT = 0, P_FILM, P_PRECONV, P_CONV3X3, P_TCONV, P_POOL, P_MA
 const char* kProfNames[P_COUNT] = {"stft_magphase", "film", "pre_conv", "conv3x3_mfma", "tconv_mfma",
                                    "avg_pool",      "mask_apply", "istft"};
 
+// Event pairs come from a pool that lass_set_profiling sizes up front: nothing is created (or allocated) inside
+// lass_separate.  When a caller lets more than kProfPairs scopes accumulate without collecting them
+// (lass_profile_get / lass_profile_reset), the surplus scopes are simply not timed.
+constexpr size_t kProfPairs = 512;
+
 struct ProfScope {
     lass_ctx* c;
     hipStream_t s;
@@ -259,14 +264,7 @@ struct ProfScope {
     hipEvent_t b = nullptr;
     bool on = false;
     ProfScope(lass_ctx* ctx, hipStream_t st, int k) : c(ctx), s(st), cls(k) {
-        if (!c->profiling) return;
-        if (c->ev_used + 2 > c->ev_pool.size()) {
-            for (int i = 0; i < 64; ++i) {
-                hipEvent_t e;
-                if (hipEventCreate(&e) != hipSuccess) return;
-                c->ev_pool.push_back(e);
-            }
-        }
+        if (!c->profiling || c->ev_used + 2 > c->ev_pool.size()) return;
         hipEvent_t a = c->ev_pool[c->ev_used++];
         b = c->ev_pool[c->ev_used++];
         (void)hipEventRecord(a, s);
@@ -456,8 +454,13 @@ size_t bump(size_t& total, size_t floats) {
     return off;
 }
 
+// The conv kernels address one clip's tensors through 32-bit buffer descriptors and byte offsets: the largest per-clip
+// tensor (decoder_block6's 64-channel concat at the full 512-bin resolution, f32) must stay below 2^31 bytes, i.e.
+// Tp <= 16352 frames, L <= 2 616 319 samples (163 s at 16 kHz).  Longer inputs go through chunk_inference.
+constexpr long kMaxSamples = 16352L * LASS_HOP - 1;
+
 int make_plan(const lass_ctx* c, int B, int L, Plan* pl) {
-    if (B <= 0 || L <= LASS_NFFT / 2) return LASS_ERR_ARG;
+    if (B <= 0 || L <= LASS_NFFT / 2 || (long)L > kMaxSamples) return LASS_ERR_ARG;
     pl->B = B; pl->L = L;
     pl->T = 1 + L / LASS_HOP;
     pl->Tp = (pl->T + 31) / 32 * 32;
@@ -490,10 +493,17 @@ int make_plan(const lass_ctx* c, int B, int L, Plan* pl) {
     return 0;
 }
 
+// Every entry that launches or allocates runs on the context's device, whatever the caller's current device is.
+int use_device(lass_ctx* c) {
+    if (!c) return LASS_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    return 0;
+}
+
 int check_ready(lass_ctx* c) {
     if (!c) return LASS_ERR_ARG;
     if (!c->finalized) return fail(c, LASS_ERR_STATE, "lass_finalize has not been called (or a parameter changed since)");
-    return 0;
+    return use_device(c);
 }
 
 const ResBlock* find_block(const lass_ctx* c, const std::string& prefix) {
@@ -746,7 +756,7 @@ int lass_finalize(lass_ctx* c, int compute_mode) {
 int lass_workspace_bytes(const lass_ctx* c, int B, int L, size_t* bytes) {
     if (!c || !bytes) return LASS_ERR_ARG;
     Plan pl;
-    if (make_plan(c, B, L, &pl)) return LASS_ERR_ARG;
+    if (make_plan(c, B, L, &pl)) return LASS_ERR_ARG;  // B < 1, L <= 512 or L beyond the 32-bit per-clip addressing limit
     *bytes = pl.total;
     return 0;
 }
@@ -778,6 +788,7 @@ int lass_film_raw(lass_ctx* c, const float* cond, int B, float* film, void* stre
 int lass_stft_magphase(lass_ctx* c, const float* wav, int B, int L, float* mag, float* cos_out, float* sin_out,
                        float* real_out, float* imag_out, void* stream) {
     if (!c || !wav || B <= 0 || L <= LASS_NFFT / 2) return fail(c, LASS_ERR_ARG, "lass_stft_magphase: bad argument");
+    if (int r = use_device(c)) return r;
     const int T = 1 + L / LASS_HOP;
     HIP_TRY(c, lass_launch_stft(wav, B, L, T, T, c->tw, c->win, mag, cos_out, sin_out, real_out, imag_out, nullptr,
                                 nullptr, nullptr, (hipStream_t)stream));
@@ -796,6 +807,7 @@ int lass_multi_stft(lass_ctx* c, const float* wav, int B, int L, int hop, int n_
         if (L <= N / 2) return fail(c, LASS_ERR_ARG, "lass_multi_stft: waveform shorter than the reflect padding");
         if (!mag[i] || !cos_out[i] || !sin_out[i]) return fail(c, LASS_ERR_ARG, "lass_multi_stft: null output");
     }
+    if (int r = use_device(c)) return r;
     HIP_TRY(c, lass_launch_multi_stft(wav, B, L, hop, n_windows, win_lengths, c->tw2k, mag, cos_out, sin_out,
                                       (hipStream_t)stream));
     return 0;
@@ -806,6 +818,7 @@ int lass_istft(lass_ctx* c, const float* real, const float* imag, int B, int T, 
     if (!c || !real || !imag || !wav || !frames_ws || B <= 0 || T <= 0 || L <= 0 ||
         (long)L + LASS_NFFT / 2 > (long)(T - 1) * LASS_HOP + LASS_NFFT)
         return fail(c, LASS_ERR_ARG, "lass_istft: bad argument");
+    if (int r = use_device(c)) return r;
     HIP_TRY(c, lass_launch_istft_frames(real, imag, B, T, c->tw, c->win, frames_ws, (hipStream_t)stream));
     HIP_TRY(c, lass_launch_istft_ola(frames_ws, B, T, L, c->win, wav, (hipStream_t)stream));
     return 0;
@@ -820,6 +833,78 @@ int lass_convblock(lass_ctx* c, const char* prefix, const float* x, int B, int H
     if (!rb) return fail(c, LASS_ERR_ARG, std::string("lass_convblock: unknown block '") + prefix + "'");
     const long HW = (long)H * W;
     return run_resblock(c, *rb, x, rb->cin * HW, B, H, W, shift, scratch, y, rb->cout * HW, (hipStream_t)stream);
+}
+
+int lass_encoder_block(lass_ctx* c, const char* name, const float* x, int B, int H, int W, const float* shift, float* y,
+                       float* pool, float* scratch, void* stream) {
+    int r = check_ready(c);
+    if (r) return r;
+    if (!name || !x || !shift || !y || !scratch || B <= 0 || H <= 0 || W <= 0)
+        return fail(c, LASS_ERR_ARG, "lass_encoder_block: bad argument");
+    for (int i = 0; i < 7; ++i) {
+        if (std::string("base.") + kEnc[i].name != name) continue;
+        const ResBlock& rb = c->enc[i];
+        const long HW = (long)H * W;
+        const bool pooled = kEnc[i].dw == 2;
+        if (pooled && (!pool || W % 2 != 0)) return fail(c, LASS_ERR_ARG, "lass_encoder_block: pool output needed, W even");
+        // same rule as lass_separate: the pool rides in conv2's epilogue when the rows divide, else its own kernel
+        const bool fuse = pooled && c->fuse_pool && (H % kEnc[i].dh) == 0;
+        hipStream_t st = (hipStream_t)stream;
+        r = run_resblock(c, rb, x, rb.cin * HW, B, H, W, shift, scratch, y, rb.cout * HW, st, fuse ? pool : nullptr,
+                         kEnc[i].dh);
+        if (r) return r;
+        if (pooled && !fuse)
+            HIP_TRY(c, lass_launch_pool(y, rb.cout * HW, B, rb.cout, H, W, kEnc[i].dh, kEnc[i].dw, pool, st));
+        return 0;
+    }
+    return fail(c, LASS_ERR_ARG, std::string("lass_encoder_block: unknown encoder '") + name + "'");
+}
+
+int lass_front_end(lass_ctx* c, const float* wav, int B, int L, float* mag, float* cos_out, float* sin_out, float* x0,
+                   void* stream) {
+    int r = check_ready(c);
+    if (r) return r;
+    if (!wav || !x0 || B <= 0 || L <= LASS_NFFT / 2) return fail(c, LASS_ERR_ARG, "lass_front_end: bad argument");
+    const int T = 1 + L / LASS_HOP, Tp = (T + 31) / 32 * 32;
+    HIP_TRY(c, lass_launch_stft(wav, B, L, T, Tp, c->tw, c->win, mag, cos_out, sin_out, nullptr, nullptr, x0, c->bn0_s,
+                                c->bn0_h, (hipStream_t)stream));
+    return 0;
+}
+
+int lass_workspace_tensor(const lass_ctx* c, int B, int L, const char* name_c, size_t* offset, int64_t shape[4],
+                          int64_t strides[4]) {
+    if (!c || !name_c || !offset || !shape || !strides) return LASS_ERR_ARG;
+    Plan pl;
+    if (make_plan(c, B, L, &pl)) return LASS_ERR_ARG;
+    const std::string name(name_c);
+    auto put = [&](size_t off, int64_t C, int64_t H, int64_t W, int64_t bs) {
+        *offset = off;
+        shape[0] = B; shape[1] = C; shape[2] = H; shape[3] = W;
+        strides[0] = bs; strides[1] = H * W; strides[2] = W; strides[3] = 1;
+        return 0;
+    };
+    const int64_t spec = (int64_t)pl.T * LASS_NBINS;
+    if (name == "mag") return put(pl.mag, 1, pl.T, LASS_NBINS, spec);
+    if (name == "cos") return put(pl.cosv, 1, pl.T, LASS_NBINS, spec);
+    if (name == "sin") return put(pl.sinv, 1, pl.T, LASS_NBINS, spec);
+    if (name == "out_real") return put(pl.oreal, 1, pl.T, LASS_NBINS, spec);
+    if (name == "out_imag") return put(pl.oimag, 1, pl.T, LASS_NBINS, spec);
+    if (name == "x0") return put(pl.x0, 1, pl.Tp, LASS_FCROP, (int64_t)pl.Tp * LASS_FCROP);
+    for (int i = 0; i < 7; ++i) {
+        const int64_t H = pl.eh[i], W = pl.ew[i], C = kEnc[i].cout;
+        if (name == kEnc[i].name) {
+            if (i == 6) return put(pl.center, C, H, W, C * H * W);
+            return put(pl.cat[5 - i] + (size_t)C * H * W * sizeof(float), C, H, W, 2 * C * H * W);  // skip half of the concat
+        }
+        if (i < 6 && name == std::string(kEnc[i].name) + ".pool")
+            return put(pl.pool[i], C, H / kEnc[i].dh, W / kEnc[i].dw, C * (H / kEnc[i].dh) * (W / kEnc[i].dw));
+    }
+    for (int d = 0; d < 6; ++d) {
+        const int64_t H = pl.eh[5 - d], W = pl.ew[5 - d], C = kDec[d].cout;
+        if (name == std::string(kDec[d].name) + ".up") return put(pl.cat[d], C, H, W, 2 * C * H * W);
+        if (name == kDec[d].name) return put(pl.decout[d], C, H, W, C * H * W);
+    }
+    return LASS_ERR_ARG;
 }
 
 int lass_upconv(lass_ctx* c, const char* name, const float* x, int B, int h, int w, const float* shift, float* y,
@@ -847,6 +932,7 @@ int lass_mask_apply(lass_ctx* c, const float* x12, const float* mag, const float
 
 int lass_sdr_stats(lass_ctx* c, const float* ref, const float* est, int B, int L, double* stats, void* stream) {
     if (!c || !ref || !est || !stats || B <= 0 || L <= 0) return fail(c, LASS_ERR_ARG, "lass_sdr_stats: bad argument");
+    if (int r = use_device(c)) return r;
     HIP_TRY(c, lass_launch_sdr(ref, est, B, L, stats, (hipStream_t)stream));
     return 0;
 }
@@ -855,6 +941,7 @@ int lass_mix_at_snr(lass_ctx* c, float* source, const float* noise, const float*
                     double* scratch, void* stream) {
     if (!c || !source || !noise || !snr_db || !mixture || !scratch || B <= 0 || L <= 0)
         return fail(c, LASS_ERR_ARG, "lass_mix_at_snr: bad argument");
+    if (int r = use_device(c)) return r;
     HIP_TRY(c, lass_launch_mix_at_snr(source, noise, snr_db, mixture, B, L, scratch, (hipStream_t)stream));
     return 0;
 }
@@ -865,7 +952,9 @@ int lass_separate(lass_ctx* c, const float* mixture, const float* condition, flo
     if (r) return r;
     if (!mixture || !condition || !out || !workspace) return fail(c, LASS_ERR_ARG, "lass_separate: null pointer");
     Plan pl;
-    if (make_plan(c, B, L, &pl)) return fail(c, LASS_ERR_ARG, "lass_separate: need B >= 1 and L > 512");
+    if (make_plan(c, B, L, &pl))
+        return fail(c, LASS_ERR_ARG, "lass_separate: need B >= 1 and 512 < L <= " + std::to_string(kMaxSamples) +
+                                         " samples per clip (longer clips: ResUNet30.chunk_inference)");
     if (workspace_bytes < pl.total)
         return fail(c, LASS_ERR_WORKSPACE, "workspace too small: need " + std::to_string(pl.total) + " bytes");
     if (((uintptr_t)workspace & 255) != 0) return fail(c, LASS_ERR_ARG, "workspace must be 256-byte aligned");
@@ -995,6 +1084,15 @@ int lass_separate(lass_ctx* c, const float* mixture, const float* condition, flo
 
 int lass_set_profiling(lass_ctx* c, int enabled) {
     if (!c) return LASS_ERR_ARG;
+    if (enabled && c->ev_pool.size() < 2 * kProfPairs) {
+        HIP_TRY(c, hipSetDevice(c->device));
+        c->pending.reserve(kProfPairs);
+        while (c->ev_pool.size() < 2 * kProfPairs) {
+            hipEvent_t e;
+            HIP_TRY(c, hipEventCreate(&e));
+            c->ev_pool.push_back(e);
+        }
+    }
     c->profiling = enabled != 0;
     return 0;
 }

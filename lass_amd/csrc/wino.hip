@@ -22,6 +22,7 @@
 #include <type_traits>
 #include <vector>
 #include "kernels.h"
+#include "pixel_ops.h"
 #include "wino_common.h"
 
 namespace {
@@ -33,29 +34,6 @@ constexpr int F_RESPRE = 128;   // with F_RES: the residual is pre_w[n]*x0 + pre
 constexpr int NTHREADS = 256;
 constexpr int KC = 8;
 constexpr int KCB = 32;  // shortcut phase: 32 channels x 4 xi per chunk (the same 128 LDS rows and 64 MFMAs as a 3x3 chunk)
-
-__device__ __forceinline__ float leaky(float v) { return fmaxf(v, 0.01f * v); }
-
-// The complex ratio mask of one time-frequency bin from its three after_conv logits (resunet.py:476-507; torchlibrosa
-// magphase clamps |M| at 1e-10); bin 512 is the zero padding of resunet.py:573, whose output is exactly 0.
-__device__ __forceinline__ void mask_pixel(const ConvArgs& p, int b, int t, int f, float l0, float l1, float l2) {
-    const size_t row = ((size_t)b * p.mask_T + t) * LASS_NBINS + f;
-    const float mask_mag = 1.f / (1.f + expf(-l0));
-    const float mr = tanhf(l1), mi = tanhf(l2);
-    const float mm = sqrtf(mr * mr + mi * mi);
-    const float den = fmaxf(mm, 1e-10f);
-    const float mc = mr / den, ms = mi / den;
-    const float ci = p.mask_cos[row], si = p.mask_sin[row];
-    const float oc = ci * mc - si * ms;
-    const float os = si * mc + ci * ms;
-    const float om = fmaxf(p.mask_mag[row] * mask_mag, 0.f);
-    p.mask_re[row] = om * oc;
-    p.mask_im[row] = om * os;
-    if (f == LASS_FCROP - 1) {
-        p.mask_re[row + 1] = 0.f;
-        p.mask_im[row + 1] = 0.f;
-    }
-}
 
 // Halo-tile staging: [KC][IR][IP] raw (activated) input, walked in channel pairs (see conv.hip Phase).
 template <int IR, int IP, int HALO, int KCH, bool PRO, bool PRE = false>

@@ -29,7 +29,7 @@ def gather_rows(local: np.ndarray, n_total: int, device=None) -> np.ndarray:
     Ragged shards are padded with NaN to the largest shard so ONE fixed-size all_gather suffices."""
     rank, ws = world()
     local = np.asarray(local, dtype=np.float64).reshape(-1, local.shape[-1] if local.ndim > 1 else 1)
-    if ws == 1:
+    if ws == 1 and not (dist.is_available() and dist.is_initialized()):
         assert local.shape[0] == n_total
         return local
     k = local.shape[1]

@@ -56,9 +56,9 @@ class Engine:
             return 1  # num_batches_tracked & co: not used by inference
         t = t.to(torch.float32).contiguous()
         shape = (c_int64 * max(1, t.dim()))(*t.shape)
-        rc = self.lib.lass_set_param(self.ctx, name.encode(), _ptr(t), shape, t.dim(), 0)
-        if t.is_cuda:
+        if t.is_cuda:  # lass_set_param copies synchronously on the NULL stream: the source must be complete first
             torch.cuda.current_stream(t.device).synchronize()
+        rc = self.lib.lass_set_param(self.ctx, name.encode(), _ptr(t), shape, t.dim(), 0)
         self.finalized = False
         return _lib.check(self.ctx, rc, f"lass_set_param({name})")
 
@@ -100,6 +100,9 @@ class Engine:
         B, L = mixture.shape
         if out is None:
             out = torch.empty_like(mixture)
+        elif (out.shape != mixture.shape or out.dtype != torch.float32 or out.device != self.device
+              or not out.is_contiguous()):
+            raise _lib.LassError(f"out must be a contiguous float32 {tuple(mixture.shape)} tensor on {self.device}")
         ws = self._workspace(B, L)
         rc = self.lib.lass_separate(self.ctx, _ptr(mixture), _ptr(condition), _ptr(out), B, L, _ptr(ws), ws.numel(),
                                     _stream(self.device))
@@ -175,6 +178,46 @@ class Engine:
                                      _stream(self.device))
         _lib.check(self.ctx, rc, "lass_convblock")
         return y
+
+    def encoder_block(self, name: str, x: torch.Tensor, shift: torch.Tensor, cout: int, down):
+        """One encoder block incl. its (fused) avg-pool: x (B,Cin,H,W) -> (y (B,Cout,H,W), pool or None)."""
+        x = self._dev(x)
+        B, _cin, H, W = x.shape
+        y = torch.empty(B, cout, H, W, dtype=torch.float32, device=self.device)
+        pool = (torch.empty(B, cout, H // down[0], W // down[1], dtype=torch.float32, device=self.device)
+                if tuple(down) != (1, 1) else None)
+        scratch = torch.empty_like(y)
+        rc = self.lib.lass_encoder_block(self.ctx, name.encode(), _ptr(x), B, H, W, _ptr(shift), _ptr(y), _ptr(pool),
+                                         _ptr(scratch), _stream(self.device))
+        _lib.check(self.ctx, rc, "lass_encoder_block")
+        return y, pool
+
+    def front_end(self, wav: torch.Tensor):
+        """(B,L) -> (mag, cos, sin (B,T,513), x0 (B,Tpad,512)): STFT + bn0 + T-pad + F-crop (resunet.py:533-552)."""
+        wav = self._dev(wav)
+        B, L = wav.shape
+        T = arch.frames_for(L)
+        mk = lambda: torch.empty(B, T, arch.N_BINS, dtype=torch.float32, device=self.device)  # noqa: E731
+        mag, cos, sin = mk(), mk(), mk()
+        x0 = torch.empty(B, arch.padded_frames(T), arch.F_CROP, dtype=torch.float32, device=self.device)
+        rc = self.lib.lass_front_end(self.ctx, _ptr(wav), B, L, _ptr(mag), _ptr(cos), _ptr(sin), _ptr(x0),
+                                     _stream(self.device))
+        _lib.check(self.ctx, rc, "lass_front_end")
+        return mag, cos, sin, x0
+
+    def workspace_tensor(self, name: str, B: int, L: int) -> torch.Tensor:
+        """View of a named intermediate that the last `separate` of shape (B, L) left in the workspace (f32 mode)."""
+        off = c_size_t()
+        shape, strides = (c_int64 * 4)(), (c_int64 * 4)()
+        rc = self.lib.lass_workspace_tensor(self.ctx, B, L, name.encode(), byref(off), shape, strides)
+        if rc < 0:
+            raise _lib.LassError(f"lass_workspace_tensor: unknown tensor '{name}' or bad shape")
+        ws = self._ws.get((B, L))
+        if ws is None:
+            raise _lib.LassError("no workspace of that shape: call separate(B, L) first")
+        assert off.value % 4 == 0
+        flat = ws.view(torch.float32)
+        return flat.as_strided(tuple(shape), tuple(strides), off.value // 4)
 
     def upconv(self, name: str, x: torch.Tensor, shift: torch.Tensor, cout: int, up) -> torch.Tensor:
         x = self._dev(x)

@@ -69,14 +69,14 @@ class DCASEEvaluator:
         source, _ = read_wav(os.path.join(self.audio_dir, f"{source}.wav"), self.sampling_rate)
         noise, _ = read_wav(os.path.join(self.audio_dir, f"{noise}.wav"), self.sampling_rate)
         source = source.copy()
-        # create audio mixture with a specific SNR level
+        # scale the noise so that the pair sits at the row's SNR (dcase_evaluator.py:77-83)
         source_power = np.mean(source ** 2)
         noise_power = np.mean(noise ** 2)
         desired_noise_power = source_power / (10 ** (snr / 10))
         scaling_factor = np.sqrt(desired_noise_power / noise_power)
         noise = noise * scaling_factor
         mixture = source + noise
-        # declipping if need be
+        # a mixture that would clip is brought to a 0.9 peak together with its source (dcase_evaluator.py:86-89)
         max_value = np.max(np.abs(mixture))
         if max_value > 1:
             source *= 0.9 / max_value

@@ -358,12 +358,14 @@ def test_sdr_stats_vs_oracle():
     assert abs(metrics.calculate_sdr(ref, 0.5 * ref) - 6.0206) < 1e-3
 
 
-def test_evaluator_matches_oracle(tmp_path, model, oracle_sd):
-    """BASELINE config 1 shape (8 synthetic mixtures) at 2 s per clip to keep the CPU oracle fast."""
+@pytest.mark.parametrize("L", [32000, 160000])
+def test_evaluator_matches_oracle(tmp_path, model, oracle_sd, L):
+    """BASELINE configs[0]: dcase_evaluator on 8 synthetic mixtures - once at its stated size (10 s @ 16 kHz) and once
+    at 2 s per clip (faster CPU oracle, different frame count)."""
     from lass_amd.audiosep import AudioSep, PrecomputedQueryEncoder
     from lass_amd.evaluator import DCASEEvaluator
     from oracle import evaluator as oev
-    n, L = 8, 32000
+    n = 8
     csv_path = synthetic.write_validation_set(str(tmp_path), n_clips=n, length=L)
     qe = PrecomputedQueryEncoder()
     pl_model = AudioSep(ss_model=model, query_encoder=qe)

@@ -1,0 +1,176 @@
+"""Stage-level GPU parity: the fused stages of the HIP path (avg-pool in conv2's epilogue, bn0/pad/crop in the STFT
+epilogue, virtual concat) held directly to the oracle AND to the taps the reference itself produced (fixture G1,
+tests/golden/g1_tiny.npz, made by tools/gen_golden.py from /root/reference/models/resunet.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from lass_amd import arch, synthetic
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _relerr(got, ref):
+    return float((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt().clamp_min(1e-30))
+
+
+@pytest.fixture(scope="module")
+def oracle_sd(synthetic_sd):
+    from oracle import resunet as orr
+    return orr.to_torch(synthetic_sd)
+
+
+@pytest.fixture(scope="module")
+def model(synthetic_sd):
+    from lass_amd.resunet import ResUNet30
+    m = ResUNet30(1, 1, 512)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synthetic_sd.items()})
+    return m.to(DEV).eval()
+
+
+ENC_CASES = [  # (encoder index, H, W): fused 2x2 pool, fused 1x2 pool (encoder_block6), odd H (stand-alone pool kernel)
+    (0, 16, 64), (1, 24, 32), (2, 12, 64), (4, 8, 32), (5, 12, 16), (5, 6, 32), (1, 9, 32), (6, 4, 8)]
+
+
+@pytest.mark.parametrize("ei,H,W", ENC_CASES)
+def test_encoder_block_and_fused_pool_vs_oracle(model, oracle_sd, ei, H, W):
+    """EncoderBlockRes1B.forward (resunet.py:186-198): block output AND F.avg_pool2d output, per block."""
+    from oracle import resunet as orr
+    e = arch.ENCODERS[ei]
+    eng = model.engine
+    g = torch.Generator().manual_seed(ei * 7919 + H * 100 + W)
+    B = 2
+    x = torch.randn(B, e.cin, H, W, generator=g)
+    cond = torch.from_numpy(synthetic.make_condition(B))
+    shift = eng.film(cond.to(DEV))
+    y, pool = eng.encoder_block("base." + e.name, x.to(DEV), shift, e.cout, e.down)
+    stem = f"{e.name}->conv_block1"
+    ref = orr.conv_block_res(oracle_sd, f"base.{e.name}.conv_block1", x, orr.film(oracle_sd, cond, stem + "->beta1"),
+                             orr.film(oracle_sd, cond, stem + "->beta2"))
+    assert _relerr(y.cpu(), ref) < 5e-6
+    if e.down == (1, 1):
+        assert pool is None
+        return
+    ref_pool = F.avg_pool2d(ref, kernel_size=e.down)
+    assert pool.shape == ref_pool.shape
+    assert _relerr(pool.cpu(), ref_pool) < 5e-6
+    # the pooled tensor must be the mean of the block output the same launch stored (fusion consistency, tight)
+    assert float((pool - F.avg_pool2d(y, kernel_size=e.down)).abs().max()) < 2e-6 * max(1.0, float(y.abs().max()))
+
+
+@pytest.mark.parametrize("L", [16000, 8000 + 77, 160000])
+def test_front_end_x0_vs_oracle(model, oracle_sd, L):
+    """resunet.py:533-552: bn0 over frequency, zero padding of T AFTER bn0 (not bn0(0)), Nyquist bin dropped."""
+    from oracle import resunet as orr
+    B = 2
+    _, mix = synthetic.make_mixtures(B, L)
+    taps = {}
+    if L <= 16000:
+        orr.forward(oracle_sd, {"mixture": torch.from_numpy(mix)[:, None],
+                                "condition": torch.from_numpy(synthetic.make_condition(B))}, taps)
+    mag, cos, sin, x0 = model.engine.front_end(torch.from_numpy(mix).to(DEV))
+    T, Tp = arch.frames_for(L), arch.padded_frames(arch.frames_for(L))
+    assert x0.shape == (B, Tp, 512)
+    assert torch.all(x0[:, T:, :] == 0)  # padded frames are exact zeros
+    if L <= 16000:
+        ref = taps["x0"][:, 0]
+        assert float((x0.cpu() - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+    else:  # full size: x0 must be the affine bn0 image of the mag the same launch wrote
+        sd = oracle_sd
+        s = sd["base.bn0.weight"] / torch.sqrt(sd["base.bn0.running_var"] + 1e-5)
+        h = sd["base.bn0.bias"] - sd["base.bn0.running_mean"] * s
+        ref = mag.cpu()[:, :, :512] * s[:512] + h[:512]
+        assert float((x0.cpu()[:, :T] - ref).abs().max()) < 1e-5 * max(1.0, float(ref.abs().max()))
+
+
+def _sample(t, n=4096):
+    f = t.detach().reshape(-1)
+    step = max(1, f.numel() // n)
+    return f[::step][:n].cpu().numpy().astype(np.float32)
+
+
+def _stats(t):
+    d = t.detach().double()
+    return np.asarray([d.sum().item(), d.abs().sum().item(), (d * d).sum().item(), float(d.numel())])
+
+
+G1_TAPS = ["encoder_block1", "encoder_block1.pool", "encoder_block2.pool", "encoder_block3", "encoder_block4.pool",
+           "encoder_block5.pool", "encoder_block6", "encoder_block6.pool", "conv_block7a", "decoder_block1.up",
+           "decoder_block1", "decoder_block3.up", "decoder_block4", "decoder_block4.up", "decoder_block5",
+           "decoder_block6.up", "out_real", "out_imag"]
+
+
+def test_hip_taps_vs_reference_fixture_g1(model, golden_dir):
+    """The HIP path's own intermediates (read in place from the workspace after lass_separate) against samples and
+    moments of the tensors /root/reference/models/resunet.py produced for the same seeded inputs (fixture G1).  Covers
+    the fused avg-pool stores, the virtual concat halves, every transposed conv and the fused output head."""
+    g = np.load(os.path.join(golden_dir, "g1_tiny.npz"))
+    B, L = 2, 16000
+    _, mix = synthetic.make_mixtures(B, L)
+    cond = synthetic.make_condition(B)
+    eng = model.engine
+    out = eng.separate(torch.from_numpy(mix).to(DEV), torch.from_numpy(cond).to(DEV))
+    torch.cuda.synchronize()
+    assert float((out.cpu() - torch.from_numpy(g["waveform"][:, 0])).pow(2).mean().sqrt()) < 2e-6
+    T = arch.frames_for(L)
+    for name in G1_TAPS:
+        t = eng.workspace_tensor(name, B, L).clone()
+        if name in ("out_real", "out_imag"):
+            t = t[:, :, :T]  # (B,1,T,513) as the reference holds it
+        scale = max(1.0, float(np.sqrt(g[name + "/stats"][2] / g[name + "/stats"][3])))
+        st = _stats(t)
+        assert st[3] == g[name + "/stats"][3], name
+        np.testing.assert_allclose(_sample(t), g[name + "/sample"], rtol=0, atol=3e-4 * scale, err_msg=name)
+        np.testing.assert_allclose(st[:3], g[name + "/stats"][:3], rtol=2e-5, atol=1e-2, err_msg=name)
+    xc = eng.workspace_tensor("conv_block7a", B, L)
+    np.testing.assert_allclose(xc.cpu().numpy(), g["x_center"], rtol=0, atol=2e-4)
+
+
+UPS_REST = [("decoder_block3", 384, 256, (2, 2), 6, 32), ("decoder_block4", 256, 128, (2, 2), 10, 64),
+            ("decoder_block2", 384, 384, (2, 2), 3, 16)]
+
+
+@pytest.mark.parametrize("name,cin,cout,up,h,w", UPS_REST)
+def test_upconv_remaining_decoders_vs_oracle(model, oracle_sd, name, cin, cout, up, h, w):
+    """The transposed convs not covered by test_gpu_parity.py::test_upconv_vs_oracle (decoders 3, 4; odd h on 2)."""
+    from oracle import resunet as orr
+    eng = model.engine
+    g = torch.Generator().manual_seed(h * 100 + w)
+    B = 2
+    x = torch.randn(B, cin, h, w, generator=g)
+    cond = torch.from_numpy(synthetic.make_condition(B))
+    shift = eng.film(cond.to(DEV))
+    y = eng.upconv("base." + name, x.to(DEV), shift, cout, up).cpu()
+    hh = F.leaky_relu(orr._bn(oracle_sd, f"base.{name}.bn1", x) + orr.film(oracle_sd, cond, f"{name}->beta1"), 0.01)
+    ref = F.conv_transpose2d(hh, oracle_sd[f"base.{name}.conv1.weight"], stride=up)
+    assert y.shape == ref.shape
+    assert _relerr(y, ref) < 2e-6
+
+
+def test_workspace_tensor_rejects_unknown_names(model):
+    from lass_amd._lib import LassError
+    eng = model.engine
+    with pytest.raises(LassError):
+        eng.workspace_tensor("no_such_tensor", 2, 16000)
+
+
+def test_separate_rejects_bad_out_and_overlong_clips(model):
+    """`out` is validated before its pointer crosses the C-ABI; clips beyond the 32-bit per-clip addressing
+    limit are refused with a message instead of silently reading zeros."""
+    from lass_amd._lib import LassError
+    eng = model.engine
+    mix = torch.zeros(2, 16000, device=DEV)
+    cond = torch.zeros(2, 512, device=DEV)
+    with pytest.raises(LassError):
+        eng.separate(mix, cond, out=torch.empty(2, 8000, device=DEV))
+    with pytest.raises(LassError):
+        eng.separate(mix, cond, out=torch.empty(2, 32000, device=DEV)[:, ::2])
+    with pytest.raises(LassError):
+        eng.separate(mix, cond, out=torch.empty(2, 16000, device=DEV, dtype=torch.float64))
+    with pytest.raises(LassError):
+        eng.workspace_bytes(1, 2616320)
+    assert eng.workspace_bytes(1, 2616319) > 0

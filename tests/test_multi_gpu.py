@@ -1,0 +1,142 @@
+"""The N > 1 path (BASELINE configs[3]): clip-sharded evaluation with ONE all-gather of per-clip metric rows,
+and bench.py's self-launch of one rank per GPU.
+
+CPU (`-m "not gpu"`): the launcher logic.  GPU (`-m gpu`): two rank processes sharing cuda:0 over gloo run
+DCASEEvaluator.__call__ and bench.py end to end; a single-rank run exercises the RCCL ("nccl") exchange itself."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env():
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["OMP_NUM_THREADS"] = "2"
+    return env
+
+
+def test_bench_parent_builds_launch_command_without_touching_torch():
+    """`python bench.py --gpus N` with no WORLD_SIZE: the parent only assembles the torch.distributed.run command
+    (one fresh rank per GPU, rendezvous on 127.0.0.1) - it must not import torch, let alone initialise a GPU."""
+    env = _env()
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, "-X", "importtime", BENCH, "--gpus", "8", "--steps", "3", "--warmup", "1",
+                        "--print-launch"], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    cmd = json.loads(r.stdout.strip().splitlines()[-1])["launch"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "8", "--steps", "3", "--warmup", "1"] or "--print-launch" in cmd
+    assert os.path.samefile(cmd[cmd.index("--master-port") + 2], BENCH)
+    imported = [ln.split("|")[-1].strip() for ln in r.stderr.splitlines() if ln.startswith("import time:")]
+    assert "torch" not in imported and "numpy" not in imported
+
+
+def test_bench_rank_refuses_mismatched_world():
+    env = _env()
+    env.update(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "4"], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+
+
+_EVAL_WORKER = r"""
+import os, sys
+root, csv_path, audio_dir, out_dir = sys.argv[1:5]
+sys.path.insert(0, root)
+import numpy as np, torch, torch.distributed as dist
+from lass_amd import synthetic
+from lass_amd.audiosep import AudioSep, PrecomputedQueryEncoder
+from lass_amd.evaluator import DCASEEvaluator
+from lass_amd.resunet import ResUNet30
+dist.init_process_group("gloo")
+rank, ws = dist.get_rank(), dist.get_world_size()
+sd = synthetic.make_state_dict()
+m = ResUNet30(1, 1, 512)
+m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+m = m.to("cuda:0").eval()
+pl_model = AudioSep(ss_model=m, query_encoder=PrecomputedQueryEncoder())
+ev = DCASEEvaluator(sampling_rate=16000, eval_indexes=csv_path, audio_dir=audio_dir, batch_size=3)
+res = ev(pl_model)
+np.save(os.path.join(out_dir, f"rows_rank{rank}.npy"), ev.last_rows)
+np.save(os.path.join(out_dir, f"means_rank{rank}.npy"), np.asarray(res))
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.gpu
+def test_sharded_evaluator_two_ranks_equals_single_rank(tmp_path):
+    """dcase_evaluator.py:65-122 sharded over 2 rank processes (both on cuda:0, backend gloo): the gathered per-clip
+    rows and the three means equal the world-size-1 run.  7 clips -> ragged shards (3 + 4) and NaN padding."""
+    from lass_amd import synthetic
+    from lass_amd.audiosep import AudioSep, PrecomputedQueryEncoder
+    from lass_amd.evaluator import DCASEEvaluator
+    from lass_amd.resunet import ResUNet30
+    n, L = 7, 24000
+    csv_path = synthetic.write_validation_set(str(tmp_path), n_clips=n, length=L)
+    audio_dir = os.path.join(str(tmp_path), "lass_validation")
+    script = os.path.join(str(tmp_path), "w.py")
+    open(script, "w").write(_EVAL_WORKER)
+    port = 29500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), script, ROOT, csv_path, audio_dir, str(tmp_path)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=_env())
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    sd = synthetic.make_state_dict()
+    m = ResUNet30(1, 1, 512)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    m = m.to("cuda:0").eval()
+    ev = DCASEEvaluator(sampling_rate=16000, eval_indexes=csv_path, audio_dir=audio_dir, batch_size=3)
+    single = np.asarray(ev(AudioSep(ss_model=m, query_encoder=PrecomputedQueryEncoder())))
+    for rank in (0, 1):
+        rows = np.load(os.path.join(str(tmp_path), f"rows_rank{rank}.npy"))
+        means = np.load(os.path.join(str(tmp_path), f"means_rank{rank}.npy"))
+        assert rows.shape == (n, 3) and not np.isnan(rows).any()
+        # same kernels on the same clips; only the batch composition differs (3+... vs 3+3+1), which the kernels do
+        # not see (eval-mode BN: no cross-clip coupling) -> bit-identical rows
+        np.testing.assert_allclose(rows, ev.last_rows, rtol=0, atol=1e-9)
+        np.testing.assert_allclose(means, single, rtol=0, atol=1e-9)
+
+
+def _bench_json(args, timeout=900):
+    env = _env()
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, BENCH] + args, capture_output=True, text=True, timeout=timeout, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_self_launches_two_ranks_on_one_gpu():
+    """`python bench.py --gpus 2` exactly as the driver calls it (no launcher around it): two fresh ranks, one JSON line,
+    the exchange step in the job.  gloo because both ranks share the one GPU of the test box (RCCL refuses that)."""
+    res = _bench_json(["--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1", "--batch", "2",
+                       "--length", "32000", "--no-cpu-baseline", "--modes", "none"])
+    assert res["n_gpus"] == 2 and res["steps"] == 2 and res["scaling"] == "weak"
+    assert res["exchange"]["ranks"] == 2 and res["exchange"]["rows"] == 4 and res["exchange"]["allgather_ms"] > 0
+    assert res["value"] == pytest.approx(2 * 2 * 2 / (res["ms_per_step"] * 2e-3), rel=1e-6)
+    assert 0 < res["roofline"]["frac"] <= 1.0
+
+
+@pytest.mark.gpu
+def test_bench_single_rank_runs_the_rccl_exchange():
+    """N=1: the per-clip metric rows still go through a torch.distributed all_gather on backend "nccl" (= RCCL), so the
+    path configs[3] relies on executes on every bench run; roofline.frac is an executed-FLOP fraction (<= 1)."""
+    res = _bench_json(["--steps", "2", "--warmup", "1", "--batch", "2", "--length", "32000", "--no-cpu-baseline",
+                       "--modes", "bf16"])
+    ex = res["exchange"]
+    assert ex.get("error") is None and ex["rccl_ranks"] == 1 and ex["rows"] == 2 and np.isfinite(ex["mean_sdr"])
+    rf = res["roofline"]
+    assert 0 < rf["frac"] <= 1.0 and rf["algorithmic_tflops"] >= rf["achieved"]
+    assert rf["winograd_mult_reduction"] == pytest.approx(2.25)
+    assert set(res["modes"]) == {"bf16"} and 0 < res["modes"]["bf16"]["frac"] <= 1.0
