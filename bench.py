@@ -195,6 +195,11 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(parent_launch(args, sys.argv[1:]))
 
+    # RCCL and the HIP runtime print banners on the C-level stdout: from here on fd 1 is stderr, and the one JSON line
+    # goes to the real stdout through the saved descriptor.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     launched = "WORLD_SIZE" in os.environ
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -391,7 +396,8 @@ def main():
             res["modes"] = modes
         if world == 1 and not args.no_cpu_baseline and args.dtype == "f32":
             res["cpu_baseline"] = cpu_baseline(sd, L, args.cpu_full)
-        print(json.dumps(res), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(res) + "\n").encode())
     if dist.is_initialized():
         dist.destroy_process_group()
 

@@ -59,6 +59,16 @@ int lass_version(void);
 /* Create a context on HIP device `device_id`.  Builds the FFT twiddle / Hann tables.
  * Replaces: ResUNet30.__init__ (resunet.py:621-637) + torchlibrosa STFT/ISTFT construction (:284-302). */
 int lass_create(lass_ctx** out, int device_id);
+/* Context for the multi-resolution-STFT separator (BASELINE configs[4]; reference intent:
+ * models/resunet_with_multistft.py:40-118,137-216 - not runnable as shipped, see DESIGN.md section 9 for the authored
+ * spec): `n_windows` periodic-Hann analysis windows (`win_lengths`, e.g. {256, 512, 2048}) at a common n_fft (2048),
+ * hop 160; one pre_conv + encoder_block1 per window, pools and skips concatenated on channels, shared trunk; the mask is
+ * applied to the `mask_window` branch and the waveform comes from an iSTFT with that window.  Parameter names are the
+ * reference module tree's (`base.pre_convs.<w>.*`, `base.encoder_block1s.<w>.conv_block1.*`,
+ * `film.encoder_block1s-><w>->conv_block1->beta1.*`, ...).  f32 compute only.  All entry points below work on either
+ * kind of context. */
+int lass_create_multistft(lass_ctx** out, int device_id, int n_fft, int n_windows, const int* win_lengths,
+                          int mask_window);
 int lass_destroy(lass_ctx* ctx);
 
 /* Last error message of this context (or of the failed lass_create when ctx == NULL). Never NULL. */
@@ -78,9 +88,11 @@ int lass_set_param(lass_ctx* ctx, const char* name, const void* data, const int6
 int lass_finalize(lass_ctx* ctx, int compute_mode);
 
 /* Bytes of workspace `lass_separate` needs for B clips of L samples.
- * Limits: B >= 1 and 512 < L <= 2 616 319 (the kernels address one clip's tensors with 32-bit byte offsets; the largest,
- * decoder_block6's concat, reaches 2^31 bytes there - 163 s at 16 kHz).  Longer clips are an LASS_ERR_ARG here and in
- * lass_separate; the reference's own long-form route, chunk_inference (resunet.py:655-714), stays available. */
+ * Limits: B >= 1, L > n_fft/2, and the largest per-clip tensor - decoder_block6's concat, (32 + 32*n_windows) channels x
+ * padded frames x n_fft/2 bins, f32 - below 4 GiB (f32 mode with the Winograd kernels) or 2 GiB (other modes): the
+ * kernels address one clip's tensors with 32-bit byte offsets.  ResUNet30: 327 s / 163 s at 16 kHz; multi-STFT model:
+ * 40.9 s at 32 kHz.  Longer clips are an LASS_ERR_ARG here and in lass_separate; the reference's own long-form route,
+ * chunk_inference (resunet.py:655-714), stays available. */
 int lass_workspace_bytes(const lass_ctx* ctx, int B, int L, size_t* bytes);
 
 /* The hot path.  mixture (B,L) f32, condition (B,512) f32 -> out (B,L) f32.
@@ -88,6 +100,14 @@ int lass_workspace_bytes(const lass_ctx* ctx, int B, int L, size_t* bytes);
  * singleton channel axis. */
 int lass_separate(lass_ctx* ctx, const float* mixture, const float* condition, float* out, int B, int L,
                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* The same path from a PRECOMPUTED analysis of the mixtures, as the reference's multi-STFT wrapper takes it
+ * (resunet_with_multistft.py:233-241: input_dict["stft_mixture_mag" / "_cos" / "_sin"][win]; producer:
+ * scripts/precompute_stfts.py:19-58 = lass_stft_components): mag[k] (B,T,n_fft/2+1) for each analysis window k in the
+ * context's order, cos / sin of the mask window only.  L = target waveform length, T = 1 + L/160. */
+int lass_separate_components(lass_ctx* ctx, const float* const* mag, const float* cos_mask, const float* sin_mask,
+                             const float* condition, float* out, int B, int L, void* workspace, size_t workspace_bytes,
+                             void* stream);
 
 /* ---- stage entry points (used by the parity tests; same kernels lass_separate launches) --------------------- */
 
@@ -107,10 +127,23 @@ int lass_stft_magphase(lass_ctx* ctx, const float* wav, int B, int L, float* mag
 int lass_multi_stft(lass_ctx* ctx, const float* wav, int B, int L, int hop, int n_windows, const int* win_lengths,
                     float* const* mag, float* const* cos_out, float* const* sin_out, void* stream);
 
-/* Inverse STFT: real, imag (B,T,513) -> wav (B,L).  frames_ws: scratch of B*T*1024 floats.
+/* `calculate_stft_components(waveform, n_fft, hop, win_length, "hann", True, "reflect")` (scripts/precompute_stfts.py:
+ * 19-58) for several win_length at one COMMON n_fft (1024 or 2048; each periodic Hann window zero-padded, centred) in one
+ * launch, torchlibrosa-magphase semantics: wav (B,L) -> mag[i], cos_out[i], sin_out[i] (B,T,n_fft/2+1), T = 1 + L/hop.
+ * This is the producer of the multi-STFT model's wire format. */
+int lass_stft_components(lass_ctx* ctx, const float* wav, int B, int L, int n_fft, int hop, int n_windows,
+                         const int* win_lengths, float* const* mag, float* const* cos_out, float* const* sin_out,
+                         void* stream);
+
+/* Inverse STFT: real, imag (B,T,513) -> wav (B,L): inverse transforms, overlap-add, division by the window-sum-square
+ * envelope and trim fused in one kernel.  frames_ws is unused since 1.1 (no frame scratch exists any more); may be NULL.
  * Replaces: torchlibrosa ISTFT.forward as called at resunet.py:510. */
 int lass_istft(lass_ctx* ctx, const float* real, const float* imag, int B, int T, int L, float* wav,
                float* frames_ws, void* stream);
+/* The same for n_fft in {1024, 2048} and a synthesis window of win_length <= n_fft (zero-padded, centred), hop 160:
+ * real, imag (B,T,n_fft/2+1) -> wav (B,L).  Replaces: ISTFT(n_fft, hop, win_length) of resunet_with_multistft.py:36-44. */
+int lass_istft_nfft(lass_ctx* ctx, const float* real, const float* imag, int B, int T, int L, int n_fft, int win_length,
+                    float* wav, void* stream);
 
 /* FiLM + BN folding for a batch of conditions: shift (B, n_shift) where n_shift = lass_film_width(ctx); column
  * layout is given by lass_film_offset().  shift[b, off+c] = bn_beta[c] - mean[c]*s[c] + (W_site cond_b + b_site)[c].
@@ -137,7 +170,9 @@ int lass_encoder_block(lass_ctx* ctx, const char* name, const float* x, int B, i
 
 /* STFT + magnitude/phase + the network-input prologue of ResUNet30_Base.forward (resunet.py:533-552): bn0 over
  * frequency, zero-padding of T to a multiple of 32 AFTER bn0, last bin dropped.  wav (B,L) -> x0 (B,Tpad,512) and,
- * where non-NULL, mag/cos/sin (B,T,513).  pre_conv (:555) is applied inside encoder_block1's staging. */
+ * where non-NULL, mag/cos/sin (B,T,513).  pre_conv (:555) is applied inside encoder_block1's staging.
+ * Multi-STFT context: x0 is (n_windows,B,Tpad,n_fft/2), one slab per analysis window; mag/cos/sin (B,T,n_fft/2+1) are
+ * the mask window's. */
 int lass_front_end(lass_ctx* ctx, const float* wav, int B, int L, float* mag, float* cos_out, float* sin_out, float* x0,
                    void* stream);
 

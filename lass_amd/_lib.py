@@ -14,6 +14,7 @@ _lib = None
 SYMBOLS = [
     ("lass_version", c_int, []),
     ("lass_create", c_int, [POINTER(c_void_p), c_int]),
+    ("lass_create_multistft", c_int, [POINTER(c_void_p), c_int, c_int, c_int, POINTER(c_int), c_int]),
     ("lass_destroy", c_int, [c_void_p]),
     ("lass_last_error", c_char_p, [c_void_p]),
     ("lass_set_param", c_int, [c_void_p, c_char_p, c_void_p, POINTER(c_int64), c_int, c_int]),
@@ -25,6 +26,11 @@ SYMBOLS = [
     ("lass_mix_at_snr", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     ("lass_multi_stft", c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, POINTER(c_int), POINTER(c_void_p),
                                 POINTER(c_void_p), POINTER(c_void_p), c_void_p]),
+    ("lass_separate_components", c_int, [c_void_p, POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                         c_int, c_void_p, c_size_t, c_void_p]),
+    ("lass_stft_components", c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, POINTER(c_int),
+                                     POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), c_void_p]),
+    ("lass_istft_nfft", c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     ("lass_istft", c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     ("lass_film", c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     ("lass_film_width", c_int, [c_void_p]),

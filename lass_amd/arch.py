@@ -198,3 +198,110 @@ def conv3x3_bytes_per_clip(length: int, bytes_per_elem: int = 4) -> int:
         elems += 2 * d.cout * hw + d.cout * hw            # conv1 over the concat
         elems += d.cout * hw + 2 * d.cout * hw + d.cout * hw  # conv2 + shortcut over the concat
     return elems * bytes_per_elem
+
+
+# ---- multi-resolution-STFT separator (BASELINE configs[4]) ----------------------------------------
+# Reference intent: /root/reference/models/resunet_with_multistft.py:40-118 (ctor), :137-216 (forward).  That file does
+# not run as shipped (missing `.film` / `Dummy*` imports; per-window spectra of 129/257/1025 bins cannot be concatenated
+# on the channel axis; one BatchNorm2d(257) is applied to all of them; decoder_block6's ConvBlockRes is built for 64
+# input channels but receives 32 + 96), so the numbers below are an AUTHORED, coherent reading of it:
+#   * every window is analysed at a COMMON n_fft = 2048 (its periodic Hann window zero-padded, centred - what
+#     `calculate_stft_components(n_fft=2048, win_length=w)` of scripts/precompute_stfts.py:19-58 computes), so every
+#     branch has 1025 bins -> 1024 after the Nyquist crop, and ONE bn0 over 1025 bins serves all branches;
+#   * one `pre_convs[w]` (1 -> 32) + `encoder_block1s[w]` (32 -> 32, (2,2)) per window; pools and skips are concatenated
+#     on channels in win_lengths order (96); encoder_block2 takes 96 channels; decoder_block6's ConvBlockRes takes
+#     32 + 96 = 128 channels; everything else is the ResUNet30 trunk;
+#   * the mask (sigmoid / tanh / magphase, resunet.py:469-495) is applied to the MASK_WINDOW (512) branch's
+#     magnitude / phase and the waveform comes from an iSTFT at n_fft 2048 with that branch's window.
+MS_N_FFT = 2048
+MS_WIN_LENGTHS: Tuple[int, ...] = (256, 512, 2048)  # config stft_win_lengths (scripts/precompute_stfts.py:573-590)
+MS_MASK_WINDOW = 512                                # resunet_with_multistft.py:185-188
+MS_N_BINS = MS_N_FFT // 2 + 1                       # 1025
+MS_F_CROP = MS_N_BINS - 1                           # 1024
+
+
+def ms_encoders(win_lengths=MS_WIN_LENGTHS) -> Tuple[EncSpec, ...]:
+    """Shared trunk encoders of the multi-STFT model (encoder_block2 widened to the fused channel count)."""
+    fused = PRE_CH * len(win_lengths)
+    return (EncSpec("encoder_block2", fused, 64, (2, 2)),) + ENCODERS[2:]
+
+
+def ms_film_sites(win_lengths=MS_WIN_LENGTHS) -> List[Tuple[str, int, bool]]:
+    """(film module name, channels, used) - get_film_meta's naming over the module tree of the multi-STFT base:
+    ModuleDict children appear as 'encoder_block1s-><win>->conv_block1->beta1'."""
+    fused = PRE_CH * len(win_lengths)
+    sites: List[Tuple[str, int, bool]] = []
+    for w in win_lengths:
+        sites.append((f"encoder_block1s->{w}->conv_block1->beta1", PRE_CH, True))
+        sites.append((f"encoder_block1s->{w}->conv_block1->beta2", PRE_CH, True))
+    for e in ms_encoders(win_lengths):
+        sites.append((f"{e.name}->conv_block1->beta1", e.cin, True))
+        sites.append((f"{e.name}->conv_block1->beta2", e.cout, True))
+    for d in DECODERS:
+        cat = 2 * d.cout if d.name != "decoder_block6" else d.cout + fused
+        sites.append((f"{d.name}->beta1", d.cin, True))
+        sites.append((f"{d.name}->beta2", d.cin, False))
+        sites.append((f"{d.name}->conv_block2->beta1", cat, True))
+        sites.append((f"{d.name}->conv_block2->beta2", d.cout, True))
+    return sites
+
+
+def ms_param_specs(input_channels: int = 1, output_channels: int = 1, condition_size: int = 512,
+                   win_lengths=MS_WIN_LENGTHS):
+    """Ordered [(state_dict key, shape, kind)] of the multi-STFT `ResUNet30` (module names of
+    resunet_with_multistft.py:40-118: `base.pre_convs.<w>`, `base.encoder_block1s.<w>.conv_block1`, ...)."""
+    fused = PRE_CH * len(win_lengths)
+    specs: List[Tuple[str, Tuple[int, ...], str]] = []
+    specs += _bn("base.bn0", MS_N_BINS)
+    for w in win_lengths:
+        specs.append((f"base.pre_convs.{w}.weight", (PRE_CH, input_channels, 1, 1), "conv_w"))
+        specs.append((f"base.pre_convs.{w}.bias", (PRE_CH,), "bias"))
+    for w in win_lengths:
+        specs += _conv_block_res(f"base.encoder_block1s.{w}.conv_block1", PRE_CH, PRE_CH)
+    for e in ms_encoders(win_lengths):
+        specs += _conv_block_res(f"base.{e.name}.conv_block1", e.cin, e.cout)
+    for d in DECODERS:
+        cat = 2 * d.cout if d.name != "decoder_block6" else d.cout + fused
+        specs.append((f"base.{d.name}.conv1.weight", (d.cin, d.cout, d.up[0], d.up[1]), "tconv_w"))
+        specs += _bn(f"base.{d.name}.bn1", d.cin)
+        specs += _conv_block_res(f"base.{d.name}.conv_block2", cat, d.cout)
+        specs += _bn(f"base.{d.name}.bn2", d.cin)
+    specs.append(("base.after_conv.weight", (output_channels * K_MASK, PRE_CH, 1, 1), "conv_w"))
+    specs.append(("base.after_conv.bias", (output_channels * K_MASK,), "bias"))
+    for name, c, _used in ms_film_sites(win_lengths):
+        specs.append((f"film.{name}.weight", (c, condition_size), "linear_w"))
+        specs.append((f"film.{name}.bias", (c,), "linear_b"))
+    return specs
+
+
+def ms_conv_layer_table(t_pad: int, win_lengths=MS_WIN_LENGTHS) -> List[Dict]:
+    """Convs of the multi-STFT model with MAC counts per clip (same row format as conv_layer_table)."""
+    fused = PRE_CH * len(win_lengths)
+    rows: List[Dict] = []
+    h, w = t_pad, MS_F_CROP
+    for wl in win_lengths:
+        rows.append(dict(name=f"pre_convs.{wl}", kind="1x1", cin=1, cout=PRE_CH, h=h, w=w, macs=h * w * PRE_CH))
+        for k in (1, 2):
+            rows.append(dict(name=f"encoder_block1s.{wl}.conv{k}", kind="3x3", cin=PRE_CH, cout=PRE_CH, h=h, w=w,
+                             macs=h * w * 9 * PRE_CH * PRE_CH))
+    skips = [(h, w)]
+    h, w = h // 2, w // 2
+    for e in ms_encoders(win_lengths):
+        rows.append(dict(name=e.name + ".conv1", kind="3x3", cin=e.cin, cout=e.cout, h=h, w=w, macs=h * w * 9 * e.cin * e.cout))
+        rows.append(dict(name=e.name + ".conv2", kind="3x3", cin=e.cout, cout=e.cout, h=h, w=w, macs=h * w * 9 * e.cout * e.cout))
+        if e.cin != e.cout:
+            rows.append(dict(name=e.name + ".shortcut", kind="1x1", cin=e.cin, cout=e.cout, h=h, w=w, macs=h * w * e.cin * e.cout))
+        skips.append((h, w))
+        h, w = h // e.down[0], w // e.down[1]
+    skips.pop()
+    for d in DECODERS:
+        cat = 2 * d.cout if d.name != "decoder_block6" else d.cout + fused
+        rows.append(dict(name=d.name + ".up", kind="tconv", cin=d.cin, cout=d.cout, h=h, w=w,
+                         macs=h * w * d.cin * d.cout * d.up[0] * d.up[1]))
+        h, w = h * d.up[0], w * d.up[1]
+        assert (h, w) == skips.pop()
+        rows.append(dict(name=d.name + ".conv1", kind="3x3", cin=cat, cout=d.cout, h=h, w=w, macs=h * w * 9 * cat * d.cout))
+        rows.append(dict(name=d.name + ".conv2", kind="3x3", cin=d.cout, cout=d.cout, h=h, w=w, macs=h * w * 9 * d.cout * d.cout))
+        rows.append(dict(name=d.name + ".shortcut", kind="1x1", cin=cat, cout=d.cout, h=h, w=w, macs=h * w * cat * d.cout))
+    rows.append(dict(name="after_conv", kind="1x1", cin=PRE_CH, cout=K_MASK, h=h, w=w, macs=h * w * PRE_CH * K_MASK))
+    return rows

@@ -30,6 +30,7 @@ const DecSpec kDec[6] = {{"decoder_block1", 384, 384, 1, 2}, {"decoder_block2", 
                          {"decoder_block5", 128, 64, 2, 2},  {"decoder_block6", 64, 32, 2, 2}};
 constexpr int kPreCh = 32;
 constexpr float kBnEps = 1e-5f;
+constexpr int kMaxBranches = LASS_MAX_STFT_WINDOWS;
 
 struct Raw {
     float* d = nullptr;
@@ -65,20 +66,36 @@ thread_local std::string g_create_err;
 
 }  // namespace
 
+// Model geometry.  variant 0 = ResUNet30 (models/resunet.py): one analysis branch, n_fft = win = 1024.
+// variant 1 = the multi-resolution-STFT separator (models/resunet_with_multistft.py under the authored spec of
+// DESIGN.md / lass_amd/arch.py): nbr analysis windows at a common n_fft, one pre_conv + encoder_block1 per window,
+// channel-concatenated pools / skips, shared trunk, mask and iSTFT on the branch `mask_br`.
+struct Geometry {
+    int variant = 0;
+    int nbr = 1;
+    int wins[kMaxBranches] = {1024, 0, 0, 0};
+    int nfft = 1024, nbins = 513, fcrop = 512;
+    int mask_br = 0;
+    int magphase_sem = 0;  // 0: base.py:83-88 clamp on |X|^2; 1: torchlibrosa magphase (precomputed-STFT wire format)
+};
+
 struct lass_ctx {
     int device = 0;
     std::string err;
+    Geometry g;
+    EncSpec E[7];  // encoder table of THIS model: E[0] is one analysis branch's block; E[1].cin = 32 * nbr
+    DecSpec D[6];
+    int dec_cat[6] = {0};              // concat channels of decoder d = D[d].cout + skip channels
+    std::string pre_name[kMaxBranches];  // "base.pre_conv" / "base.pre_convs.<win>"
     std::map<std::string, Raw> raw;
     bool finalized = false;
-    float2* tw = nullptr;
-    float* win = nullptr;
-    float2* tw2k = nullptr;  // 2048-point twiddles for the multi-resolution analysis (lass_multi_stft)
+    float2* tw2k = nullptr;  // (cos, sin)(2 pi k / 2048): twiddles of every transform size + the Hann windows
     std::vector<Site> sites;
     std::map<std::string, int> site_idx;
     int n_shift = 0;
     float *film_W = nullptr, *film_b = nullptr, *bn_scale = nullptr, *bn_base = nullptr;
     float *bn0_s = nullptr, *bn0_h = nullptr;
-    std::vector<ResBlock> enc, dec;  // 7 + 6
+    std::vector<ResBlock> enc, dec;  // enc: nbr branch blocks (encoder_block1[s]) then the 6 trunk blocks; dec: 6
     int dec_site[6] = {0};           // decoder_blockN->beta1
     void* up16[6] = {nullptr};       // bf16 transposed-conv weights (hi) per decoder, bf16 modes only
     void* up16l[6] = {nullptr};      // lo halves (LASS_COMPUTE_BF16X3)
@@ -147,13 +164,38 @@ int add_site(lass_ctx* c, const std::string& film, int C) {
     return (int)c->sites.size() - 1;
 }
 
+const ResBlock& trunk_block(const lass_ctx* c, int i) { return c->enc[c->g.nbr - 1 + i]; }  // i = 1..6 (E[i])
+
 void build_arch(lass_ctx* c) {
+    const Geometry& g = c->g;
     c->sites.clear();
     c->site_idx.clear();
     c->n_shift = 0;
     c->enc.clear();
     c->dec.clear();
-    for (const auto& e : kEnc) {
+    for (int i = 0; i < 7; ++i) c->E[i] = kEnc[i];
+    for (int i = 0; i < 6; ++i) c->D[i] = kDec[i];
+    c->E[1].cin = kPreCh * g.nbr;
+    for (int k = 0; k < g.nbr; ++k) {  // analysis branches
+        ResBlock rb;
+        std::string film;
+        if (g.variant == 0) {
+            rb.prefix = "base.encoder_block1.conv_block1";
+            film = "encoder_block1->conv_block1";
+            c->pre_name[k] = "base.pre_conv";
+        } else {
+            const std::string w = std::to_string(g.wins[k]);
+            rb.prefix = "base.encoder_block1s." + w + ".conv_block1";
+            film = "encoder_block1s->" + w + "->conv_block1";
+            c->pre_name[k] = "base.pre_convs." + w;
+        }
+        rb.cin = rb.cout = kPreCh;
+        rb.s1 = add_site(c, film + "->beta1", kPreCh);
+        rb.s2 = add_site(c, film + "->beta2", kPreCh);
+        c->enc.push_back(rb);
+    }
+    for (int i = 1; i < 7; ++i) {
+        const EncSpec& e = c->E[i];
         ResBlock rb;
         rb.prefix = std::string("base.") + e.name + ".conv_block1";
         rb.cin = e.cin;
@@ -163,13 +205,15 @@ void build_arch(lass_ctx* c) {
         c->enc.push_back(rb);
     }
     for (int i = 0; i < 6; ++i) {
-        const auto& d = kDec[i];
+        const auto& d = c->D[i];
+        const int e = 5 - i;
+        c->dec_cat[i] = d.cout + c->E[e].cout * (e == 0 ? g.nbr : 1);  // torch.cat((x, skip), 1)
         c->dec_site[i] = add_site(c, std::string(d.name) + "->beta1", d.cin);
         ResBlock rb;
         rb.prefix = std::string("base.") + d.name + ".conv_block2";
-        rb.cin = 2 * d.cout;
+        rb.cin = c->dec_cat[i];
         rb.cout = d.cout;
-        rb.s1 = add_site(c, std::string(d.name) + "->conv_block2->beta1", 2 * d.cout);
+        rb.s1 = add_site(c, std::string(d.name) + "->conv_block2->beta1", rb.cin);
         rb.s2 = add_site(c, std::string(d.name) + "->conv_block2->beta2", d.cout);
         c->dec.push_back(rb);
     }
@@ -181,9 +225,11 @@ std::vector<int64_t> expected_shape(const lass_ctx* c, const std::string& name) 
         return ends_with(n, ".weight") || ends_with(n, ".bias") || ends_with(n, ".running_mean") ||
                ends_with(n, ".running_var");
     };
-    if (starts_with(name, "base.bn0.") && bn_field(name)) return {LASS_NBINS};
-    if (name == "base.pre_conv.weight") return {kPreCh, 1, 1, 1};
-    if (name == "base.pre_conv.bias") return {kPreCh};
+    if (starts_with(name, "base.bn0.") && bn_field(name)) return {c->g.nbins};
+    for (int k = 0; k < c->g.nbr; ++k) {
+        if (name == c->pre_name[k] + ".weight") return {kPreCh, 1, 1, 1};
+        if (name == c->pre_name[k] + ".bias") return {kPreCh};
+    }
     if (name == "base.after_conv.weight") return {3, kPreCh, 1, 1};
     if (name == "base.after_conv.bias") return {3};
     auto res_block = [&](const ResBlock& rb) -> std::vector<int64_t> {
@@ -205,9 +251,10 @@ std::vector<int64_t> expected_shape(const lass_ctx* c, const std::string& name) 
     for (int i = 0; i < 6; ++i) {
         auto s = res_block(c->dec[i]);
         if (!s.empty()) return s;
-        const std::string p = std::string("base.") + kDec[i].name;
-        if (name == p + ".conv1.weight") return {kDec[i].cin, kDec[i].cout, kDec[i].uh, kDec[i].uw};
-        if (starts_with(name, (p + ".bn1.").c_str()) && bn_field(name)) return {kDec[i].cin};
+        const DecSpec& d = c->D[i];
+        const std::string p = std::string("base.") + d.name;
+        if (name == p + ".conv1.weight") return {d.cin, d.cout, d.uh, d.uw};
+        if (starts_with(name, (p + ".bn1.").c_str()) && bn_field(name)) return {d.cin};
     }
     if (starts_with(name, "film.")) {
         for (const auto& s : c->sites) {
@@ -310,12 +357,22 @@ struct MaskHead {
     float* oreal;
     float* oimag;
     int T;
+    int nbins;
+};
+
+// encoder_block1[s] input: the block input is pre_conv(x0) (1 -> 32 channels, resunet.py:555), formed while staging
+struct PreConv {
+    const float* x0;
+    const float* w;
+    const float* b;
 };
 
 int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int B, int H, int W, const float* shift,
                  float* a2, float* out, long out_bs, hipStream_t st, float* pool_out = nullptr, int pool_h = 2,
-                 const float* x0 = nullptr, const MaskHead* mh = nullptr, const CatCopies* skip_out = nullptr,
-                 const CatCopies* cat_in = nullptr, const Site* act_out = nullptr, const CatCopies* pool_copies = nullptr) {
+                 const PreConv* pre = nullptr, const MaskHead* mh = nullptr, const CatCopies* skip_out = nullptr,
+                 const CatCopies* cat_in = nullptr, const Site* act_out = nullptr, const CatCopies* pool_copies = nullptr,
+                 long pool_bs = 0) {
+    const float* x0 = pre ? pre->x0 : nullptr;
     const Site& s1 = c->sites[rb.s1];
     const Site& s2 = c->sites[rb.s2];
     const long HW = (long)H * W;
@@ -326,7 +383,7 @@ int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int
     p.out = a2; p.out_bs = rb.cout * HW; p.B = B; p.H = H; p.W = W;
     if (x0) {
         p.in = x0; p.in_bs = HW;
-        p.pre_w = rawp(c, "base.pre_conv.weight"); p.pre_b = rawp(c, "base.pre_conv.bias");
+        p.pre_w = pre->w; p.pre_b = pre->b;
     }
     p.w_wino = rb.u1;
     p.w_bf16 = rb.b1; p.w_bf16_lo = rb.b1l;
@@ -352,13 +409,13 @@ int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int
     ConvArgs q;
     q.in = a2; q.in_bs = rb.cout * HW; q.Cin = rb.cout; q.w = rb.w2; q.Nw = rb.cout; q.N = rb.cout;
     q.out = out; q.out_bs = out_bs; q.B = B; q.H = H; q.W = W;
-    q.pool_out = pool_out; q.pool_h = pool_h;
+    q.pool_out = pool_out; q.pool_h = pool_h; q.pool_bs = pool_bs;
     q.w_wino = rb.u2; q.w2_wino = rb.usc;
     if (mh) {  // the block output is consumed by the fused head and never written
         q.out = nullptr;
         q.mask_w = rawp(c, "base.after_conv.weight"); q.mask_b = rawp(c, "base.after_conv.bias");
         q.mask_mag = mh->mag; q.mask_cos = mh->cosv; q.mask_sin = mh->sinv;
-        q.mask_re = mh->oreal; q.mask_im = mh->oimag; q.mask_T = mh->T;
+        q.mask_re = mh->oreal; q.mask_im = mh->oimag; q.mask_T = mh->T; q.mask_nbins = mh->nbins;
     }
     q.w_bf16 = rb.b2; q.w2_bf16 = rb.bsc16; q.w_bf16_lo = rb.b2l; q.w2_bf16_lo = rb.bscl;
     const bool bf2 = bf1;  // conv1 and conv2 of a block share shape and mode: both or neither
@@ -389,7 +446,7 @@ int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int
         q.res = x; q.res_bs = x_bs;
         if (x0) {
             q.res = x0; q.res_bs = HW;
-            q.pre_w = rawp(c, "base.pre_conv.weight"); q.pre_b = rawp(c, "base.pre_conv.bias");
+            q.pre_w = pre->w; q.pre_b = pre->b;
         }
         if (bf2)
             HIP_TRY(c, lass_launch_conv_bf16(x0 ? CONV2_IDENT_PRE : CONV2_IDENT, q, st));
@@ -411,7 +468,7 @@ int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int
 
 int run_upconv(lass_ctx* c, int di, const float* x, int B, int h, int w, const float* shift, float* out, long out_bs,
                hipStream_t st, const CatCopies* cb = nullptr, bool x_is_act_bf16 = false) {
-    const DecSpec& d = kDec[di];
+    const DecSpec& d = c->D[di];
     const Site& s = c->sites[c->dec_site[di]];
     ConvArgs p;
     p.in = x; p.in_bs = (long)d.cin * h * w; p.Cin = d.cin;
@@ -444,7 +501,7 @@ int run_upconv(lass_ctx* c, int di, const float* x, int B, int h, int w, const f
 struct Plan {
     int B, L, T, Tp;
     size_t total = 0;
-    size_t mag, cosv, sinv, x0, shift, xpre, a2, cat[6], pool[6], center, decout[6], oreal, oimag, frames;
+    size_t mag, cosv, sinv, x0[kMaxBranches], shift, xpre, a2, cat[6], pool[6], center, decout[6], oreal, oimag;
     int eh[7], ew[7];  // encoder block spatial sizes
 };
 
@@ -454,42 +511,45 @@ size_t bump(size_t& total, size_t floats) {
     return off;
 }
 
-// The conv kernels address one clip's tensors through 32-bit buffer descriptors and byte offsets: the largest per-clip
-// tensor (decoder_block6's 64-channel concat at the full 512-bin resolution, f32) must stay below 2^31 bytes, i.e.
-// Tp <= 16352 frames, L <= 2 616 319 samples (163 s at 16 kHz).  Longer inputs go through chunk_inference.
-constexpr long kMaxSamples = 16352L * LASS_HOP - 1;
-
+// The conv kernels address one clip's tensors through 32-bit buffer descriptors and byte offsets, so the largest per-clip
+// tensor (decoder_block6's concat at full resolution, f32) bounds the clip length: below 4 GiB for the f32 Winograd
+// kernels (all offset arithmetic unsigned), below 2 GiB for the direct and bf16 kernels.  ResUNet30 at 16 kHz:
+// 131 072 B per frame -> 2^31 at 16 384 frames (163 s); the multi-STFT model (128 ch x 1024 bins): 524 288 B per frame ->
+// 2^32 at 8 192 frames (40.9 s at 32 kHz).  Longer inputs go through chunk_inference.
 int make_plan(const lass_ctx* c, int B, int L, Plan* pl) {
-    if (B <= 0 || L <= LASS_NFFT / 2 || (long)L > kMaxSamples) return LASS_ERR_ARG;
+    const Geometry& g = c->g;
+    if (B <= 0 || L <= g.nfft / 2) return LASS_ERR_ARG;
     pl->B = B; pl->L = L;
     pl->T = 1 + L / LASS_HOP;
     pl->Tp = (pl->T + 31) / 32 * 32;
+    const size_t clip_max = (size_t)c->dec_cat[5] * pl->Tp * g.fcrop * sizeof(float);
+    const size_t limit = (c->compute_mode == LASS_COMPUTE_F32 && c->wino) ? 0xFFFF0000ull : 0x7FFFFFFFull;
+    if (clip_max > limit) return LASS_ERR_ARG;
     size_t& t = pl->total;
     t = 0;
-    const size_t spec = (size_t)B * pl->T * LASS_NBINS;
+    const size_t spec = (size_t)B * pl->T * g.nbins;
     pl->mag = bump(t, spec); pl->cosv = bump(t, spec); pl->sinv = bump(t, spec);
-    pl->x0 = bump(t, (size_t)B * pl->Tp * LASS_FCROP);
+    for (int k = 0; k < g.nbr; ++k) pl->x0[k] = bump(t, (size_t)B * pl->Tp * g.fcrop);
     pl->shift = bump(t, (size_t)B * c->n_shift);
-    pl->xpre = bump(t, (size_t)B * kPreCh * pl->Tp * LASS_FCROP);
-    int h = pl->Tp, w = LASS_FCROP;
+    pl->xpre = bump(t, c->fuse_preconv ? 64 : (size_t)B * kPreCh * pl->Tp * g.fcrop);
+    int h = pl->Tp, w = g.fcrop;
     size_t a2max = 0;
     for (int i = 0; i < 7; ++i) {
         pl->eh[i] = h; pl->ew[i] = w;
-        const size_t o = (size_t)B * kEnc[i].cout * h * w;
+        const size_t o = (size_t)B * c->E[i].cout * h * w;
         if (o > a2max) a2max = o;
-        h /= kEnc[i].dh; w /= kEnc[i].dw;
-        if (i < 6) pl->pool[i] = bump(t, (size_t)B * kEnc[i].cout * h * w);
+        h /= c->E[i].dh; w /= c->E[i].dw;
+        if (i < 6) pl->pool[i] = bump(t, (size_t)B * c->E[i].cout * (i == 0 ? g.nbr : 1) * h * w);
     }
-    pl->center = bump(t, (size_t)B * kEnc[6].cout * pl->eh[6] * pl->ew[6]);
+    pl->center = bump(t, (size_t)B * c->E[6].cout * pl->eh[6] * pl->ew[6]);
     for (int d = 0; d < 6; ++d) {
         const int e = 5 - d;  // decoder d concatenates the skip of encoder e
         const size_t hw = (size_t)pl->eh[e] * pl->ew[e];
-        pl->cat[d] = bump(t, (size_t)B * 2 * kDec[d].cout * hw);
-        pl->decout[d] = bump(t, (size_t)B * kDec[d].cout * hw);
+        pl->cat[d] = bump(t, (size_t)B * c->dec_cat[d] * hw);
+        pl->decout[d] = bump(t, (size_t)B * c->D[d].cout * hw);
     }
     pl->a2 = bump(t, a2max);
     pl->oreal = bump(t, spec); pl->oimag = bump(t, spec);
-    pl->frames = bump(t, (size_t)B * pl->T * LASS_NFFT);
     return 0;
 }
 
@@ -516,11 +576,11 @@ const ResBlock* find_block(const lass_ctx* c, const std::string& prefix) {
 
 extern "C" {
 
-int lass_version(void) { return 100; }
+int lass_version(void) { return 10100; }  // 1.1.0: multi-STFT model, fused iSTFT, graph replay
 
 const char* lass_last_error(const lass_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
-int lass_create(lass_ctx** out, int device_id) {
+static int create_impl(lass_ctx** out, int device_id, const Geometry& geom) {
     if (!out) return LASS_ERR_ARG;
     *out = nullptr;
     int ndev = 0;
@@ -546,6 +606,7 @@ int lass_create(lass_ctx** out, int device_id) {
     }
     lass_ctx* c = new lass_ctx();
     c->device = device_id;
+    c->g = geom;
     if (const char* e = getenv("LASS_WINO")) c->wino = atoi(e) != 0;
     if (const char* e = getenv("LASS_FUSE_POOL")) c->fuse_pool = atoi(e) != 0;
     if (const char* e = getenv("LASS_FUSE_MASK")) c->fuse_mask = atoi(e) != 0;
@@ -559,25 +620,14 @@ int lass_create(lass_ctx** out, int device_id) {
         delete c;
         return LASS_ERR_HIP;
     }
-    // FFT twiddles and periodic Hann window, evaluated in double on the host.
-    std::vector<float2> tw(LASS_NFFT);
-    std::vector<float> win(LASS_NFFT);
-    for (int k = 0; k < LASS_NFFT; ++k) {
-        const double a = 2.0 * M_PI * k / LASS_NFFT;
-        tw[k] = make_float2((float)std::cos(a), (float)std::sin(a));
-        win[k] = (float)(0.5 - 0.5 * std::cos(a));
-    }
+    // FFT twiddles (the periodic Hann windows are read off the same table), evaluated in double on the host.
     std::vector<float2> tw2k(2048);
     for (int k = 0; k < 2048; ++k) {
         const double a = 2.0 * M_PI * k / 2048.0;
         tw2k[k] = make_float2((float)std::cos(a), (float)std::sin(a));
     }
     if (hipMalloc((void**)&c->tw2k, sizeof(float2) * 2048) != hipSuccess ||
-        hipMemcpy(c->tw2k, tw2k.data(), sizeof(float2) * 2048, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMalloc((void**)&c->tw, sizeof(float2) * LASS_NFFT) != hipSuccess ||
-        hipMalloc((void**)&c->win, sizeof(float) * LASS_NFFT) != hipSuccess ||
-        hipMemcpy(c->tw, tw.data(), sizeof(float2) * LASS_NFFT, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(c->win, win.data(), sizeof(float) * LASS_NFFT, hipMemcpyHostToDevice) != hipSuccess) {
+        hipMemcpy(c->tw2k, tw2k.data(), sizeof(float2) * 2048, hipMemcpyHostToDevice) != hipSuccess) {
         g_create_err = "allocating FFT tables failed";
         delete c;
         return LASS_ERR_HIP;
@@ -586,14 +636,47 @@ int lass_create(lass_ctx** out, int device_id) {
     return 0;
 }
 
+int lass_create(lass_ctx** out, int device_id) { return create_impl(out, device_id, Geometry()); }
+
+int lass_create_multistft(lass_ctx** out, int device_id, int n_fft, int n_windows, const int* win_lengths,
+                          int mask_window) {
+    if (!out) return LASS_ERR_ARG;
+    *out = nullptr;
+    Geometry g;
+    g.variant = 1;
+    g.magphase_sem = 1;
+    if (n_fft != 2048 || n_windows < 1 || n_windows > kMaxBranches || !win_lengths) {
+        g_create_err = "lass_create_multistft: n_fft must be 2048 and 1 <= n_windows <= 4";
+        return LASS_ERR_ARG;
+    }
+    g.nfft = n_fft; g.nbins = n_fft / 2 + 1; g.fcrop = n_fft / 2; g.nbr = n_windows; g.mask_br = -1;
+    for (int k = 0; k < n_windows; ++k) {
+        const int w = win_lengths[k];
+        if (w < 32 || w > n_fft || (2048 % w) != 0) {
+            g_create_err = "lass_create_multistft: window lengths must be powers of two in [32, n_fft]";
+            return LASS_ERR_ARG;
+        }
+        for (int j = 0; j < k; ++j)
+            if (g.wins[j] == w) {
+                g_create_err = "lass_create_multistft: duplicate window length";
+                return LASS_ERR_ARG;
+            }
+        g.wins[k] = w;
+        if (w == mask_window) g.mask_br = k;
+    }
+    if (g.mask_br < 0) {
+        g_create_err = "lass_create_multistft: mask_window is not one of the analysis windows";
+        return LASS_ERR_ARG;
+    }
+    return create_impl(out, device_id, g);
+}
+
 int lass_destroy(lass_ctx* c) {
     if (!c) return LASS_ERR_ARG;
     (void)hipSetDevice(c->device);
     free_owned(c);
     for (auto& kv : c->raw) (void)hipFree(kv.second.d);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
-    (void)hipFree(c->tw);
-    (void)hipFree(c->win);
     (void)hipFree(c->tw2k);
     delete c;
     return 0;
@@ -632,6 +715,8 @@ int lass_finalize(lass_ctx* c, int compute_mode) {
     if (!c) return LASS_ERR_ARG;
     if (compute_mode != LASS_COMPUTE_F32 && compute_mode != LASS_COMPUTE_BF16 && compute_mode != LASS_COMPUTE_BF16X3)
         return fail(c, LASS_ERR_ARG, "unsupported compute mode");
+    if (c->g.variant != 0 && compute_mode != LASS_COMPUTE_F32)
+        return fail(c, LASS_ERR_ARG, "the multi-STFT model computes in f32 only");
     c->compute_mode = compute_mode;
     HIP_TRY(c, hipSetDevice(c->device));
     free_owned(c);
@@ -646,7 +731,7 @@ int lass_finalize(lass_ctx* c, int compute_mode) {
     // -- BN folding for the 32 live sites + bn0, FiLM concatenation
     if (dev_alloc(c, &c->bn_scale, c->n_shift) || dev_alloc(c, &c->bn_base, c->n_shift) ||
         dev_alloc(c, &c->film_W, (size_t)c->n_shift * LASS_COND) || dev_alloc(c, &c->film_b, c->n_shift) ||
-        dev_alloc(c, &c->bn0_s, LASS_NBINS) || dev_alloc(c, &c->bn0_h, LASS_NBINS))
+        dev_alloc(c, &c->bn0_s, c->g.nbins) || dev_alloc(c, &c->bn0_h, c->g.nbins))
         return LASS_ERR_HIP;
     for (const auto& s : c->sites) {
         const float *g = need(s.bn + ".weight"), *b = need(s.bn + ".bias"), *m = need(s.bn + ".running_mean"),
@@ -662,11 +747,11 @@ int lass_finalize(lass_ctx* c, int compute_mode) {
         const float *g = need("base.bn0.weight"), *b = need("base.bn0.bias"), *m = need("base.bn0.running_mean"),
                     *v = need("base.bn0.running_var");
         if (!g || !b || !m || !v) return LASS_ERR_STATE;
-        HIP_TRY(c, lass_launch_bnfold(g, b, m, v, LASS_NBINS, kBnEps, c->bn0_s, c->bn0_h, st));
+        HIP_TRY(c, lass_launch_bnfold(g, b, m, v, c->g.nbins, kBnEps, c->bn0_s, c->bn0_h, st));
     }
-    if (!need("base.pre_conv.weight") || !need("base.pre_conv.bias") || !need("base.after_conv.weight") ||
-        !need("base.after_conv.bias"))
-        return LASS_ERR_STATE;
+    for (int k = 0; k < c->g.nbr; ++k)
+        if (!need(c->pre_name[k] + ".weight") || !need(c->pre_name[k] + ".bias")) return LASS_ERR_STATE;
+    if (!need("base.after_conv.weight") || !need("base.after_conv.bias")) return LASS_ERR_STATE;
     // -- conv weights -> [cin][tap][cout]
     auto prep = [&](ResBlock& rb) -> int {
         const float *w1 = need(rb.prefix + ".conv1.weight"), *w2 = need(rb.prefix + ".conv2.weight");
@@ -731,7 +816,7 @@ int lass_finalize(lass_ctx* c, int compute_mode) {
     for (auto& rb : c->enc) { int r = prep(rb); if (r) return r; }
     for (auto& rb : c->dec) { int r = prep(rb); if (r) return r; }
     for (int i = 0; i < 6; ++i) {
-        const auto& d = kDec[i];
+        const auto& d = c->D[i];
         const float* wu = need(std::string("base.") + d.name + ".conv1.weight");
         if (!wu) return LASS_ERR_STATE;
         c->up16[i] = c->up16l[i] = nullptr;
@@ -790,8 +875,31 @@ int lass_stft_magphase(lass_ctx* c, const float* wav, int B, int L, float* mag, 
     if (!c || !wav || B <= 0 || L <= LASS_NFFT / 2) return fail(c, LASS_ERR_ARG, "lass_stft_magphase: bad argument");
     if (int r = use_device(c)) return r;
     const int T = 1 + L / LASS_HOP;
-    HIP_TRY(c, lass_launch_stft(wav, B, L, T, T, c->tw, c->win, mag, cos_out, sin_out, real_out, imag_out, nullptr,
-                                nullptr, nullptr, (hipStream_t)stream));
+    StftBranch br;
+    br.wlen = LASS_NFFT; br.mag = mag; br.cosv = cos_out; br.sinv = sin_out; br.real = real_out; br.imag = imag_out;
+    HIP_TRY(c, lass_launch_stft2(wav, B, L, LASS_NFFT, LASS_HOP, T, T, 1, &br, 0, nullptr, nullptr, c->tw2k,
+                                 (hipStream_t)stream));
+    return 0;
+}
+
+int lass_stft_components(lass_ctx* c, const float* wav, int B, int L, int n_fft, int hop, int n_windows,
+                         const int* win_lengths, float* const* mag, float* const* cos_out, float* const* sin_out,
+                         void* stream) {
+    if (!c || !wav || !win_lengths || !mag || !cos_out || !sin_out || B <= 0 || hop <= 0 || n_windows <= 0 ||
+        n_windows > LASS_MAX_STFT_WINDOWS || (n_fft != 1024 && n_fft != 2048) || L <= n_fft / 2)
+        return fail(c, LASS_ERR_ARG, "lass_stft_components: bad argument (n_fft 1024 or 2048, at most 4 windows, L > n_fft/2)");
+    StftBranch br[LASS_MAX_STFT_WINDOWS];
+    for (int i = 0; i < n_windows; ++i) {
+        const int w = win_lengths[i];
+        if (w < 32 || w > n_fft || (2048 % w) != 0)
+            return fail(c, LASS_ERR_ARG, "lass_stft_components: window lengths must be powers of two in [32, n_fft]");
+        if (!mag[i] || !cos_out[i] || !sin_out[i]) return fail(c, LASS_ERR_ARG, "lass_stft_components: null output");
+        br[i].wlen = w; br[i].mag = mag[i]; br[i].cosv = cos_out[i]; br[i].sinv = sin_out[i];
+    }
+    if (int r = use_device(c)) return r;
+    const int T = 1 + L / hop;
+    HIP_TRY(c, lass_launch_stft2(wav, B, L, n_fft, hop, T, T, n_windows, br, 1, nullptr, nullptr, c->tw2k,
+                                 (hipStream_t)stream));
     return 0;
 }
 
@@ -815,12 +923,18 @@ int lass_multi_stft(lass_ctx* c, const float* wav, int B, int L, int hop, int n_
 
 int lass_istft(lass_ctx* c, const float* real, const float* imag, int B, int T, int L, float* wav, float* frames_ws,
                void* stream) {
-    if (!c || !real || !imag || !wav || !frames_ws || B <= 0 || T <= 0 || L <= 0 ||
-        (long)L + LASS_NFFT / 2 > (long)(T - 1) * LASS_HOP + LASS_NFFT)
+    (void)frames_ws;  // the fused kernel needs no frame scratch (kept in the signature for ABI stability; may be NULL)
+    return lass_istft_nfft(c, real, imag, B, T, L, LASS_NFFT, LASS_NFFT, wav, stream);
+}
+
+int lass_istft_nfft(lass_ctx* c, const float* real, const float* imag, int B, int T, int L, int n_fft, int win_length,
+                    float* wav, void* stream) {
+    if (!c || !real || !imag || !wav || B <= 0 || T <= 0 || L <= 0 || (n_fft != 1024 && n_fft != 2048) ||
+        win_length < 32 || win_length > n_fft || (2048 % win_length) != 0 ||
+        (long)L + n_fft / 2 > (long)(T - 1) * LASS_HOP + n_fft)
         return fail(c, LASS_ERR_ARG, "lass_istft: bad argument");
     if (int r = use_device(c)) return r;
-    HIP_TRY(c, lass_launch_istft_frames(real, imag, B, T, c->tw, c->win, frames_ws, (hipStream_t)stream));
-    HIP_TRY(c, lass_launch_istft_ola(frames_ws, B, T, L, c->win, wav, (hipStream_t)stream));
+    HIP_TRY(c, lass_launch_istft2(real, imag, B, T, L, n_fft, win_length, LASS_HOP, c->tw2k, wav, (hipStream_t)stream));
     return 0;
 }
 
@@ -841,20 +955,19 @@ int lass_encoder_block(lass_ctx* c, const char* name, const float* x, int B, int
     if (r) return r;
     if (!name || !x || !shift || !y || !scratch || B <= 0 || H <= 0 || W <= 0)
         return fail(c, LASS_ERR_ARG, "lass_encoder_block: bad argument");
-    for (int i = 0; i < 7; ++i) {
-        if (std::string("base.") + kEnc[i].name != name) continue;
-        const ResBlock& rb = c->enc[i];
+    for (size_t bi = 0; bi < c->enc.size(); ++bi) {
+        const ResBlock& rb = c->enc[bi];
+        if (rb.prefix != std::string(name) + ".conv_block1") continue;
+        const EncSpec& e = c->E[bi < (size_t)c->g.nbr ? 0 : bi - c->g.nbr + 1];
         const long HW = (long)H * W;
-        const bool pooled = kEnc[i].dw == 2;
+        const bool pooled = e.dw == 2;
         if (pooled && (!pool || W % 2 != 0)) return fail(c, LASS_ERR_ARG, "lass_encoder_block: pool output needed, W even");
         // same rule as lass_separate: the pool rides in conv2's epilogue when the rows divide, else its own kernel
-        const bool fuse = pooled && c->fuse_pool && (H % kEnc[i].dh) == 0;
+        const bool fuse = pooled && c->fuse_pool && (H % e.dh) == 0;
         hipStream_t st = (hipStream_t)stream;
-        r = run_resblock(c, rb, x, rb.cin * HW, B, H, W, shift, scratch, y, rb.cout * HW, st, fuse ? pool : nullptr,
-                         kEnc[i].dh);
+        r = run_resblock(c, rb, x, rb.cin * HW, B, H, W, shift, scratch, y, rb.cout * HW, st, fuse ? pool : nullptr, e.dh);
         if (r) return r;
-        if (pooled && !fuse)
-            HIP_TRY(c, lass_launch_pool(y, rb.cout * HW, B, rb.cout, H, W, kEnc[i].dh, kEnc[i].dw, pool, st));
+        if (pooled && !fuse) HIP_TRY(c, lass_launch_pool(y, rb.cout * HW, B, rb.cout, H, W, e.dh, e.dw, pool, st));
         return 0;
     }
     return fail(c, LASS_ERR_ARG, std::string("lass_encoder_block: unknown encoder '") + name + "'");
@@ -864,10 +977,17 @@ int lass_front_end(lass_ctx* c, const float* wav, int B, int L, float* mag, floa
                    void* stream) {
     int r = check_ready(c);
     if (r) return r;
-    if (!wav || !x0 || B <= 0 || L <= LASS_NFFT / 2) return fail(c, LASS_ERR_ARG, "lass_front_end: bad argument");
+    const Geometry& g = c->g;
+    if (!wav || !x0 || B <= 0 || L <= g.nfft / 2) return fail(c, LASS_ERR_ARG, "lass_front_end: bad argument");
     const int T = 1 + L / LASS_HOP, Tp = (T + 31) / 32 * 32;
-    HIP_TRY(c, lass_launch_stft(wav, B, L, T, Tp, c->tw, c->win, mag, cos_out, sin_out, nullptr, nullptr, x0, c->bn0_s,
-                                c->bn0_h, (hipStream_t)stream));
+    StftBranch br[kMaxBranches];
+    for (int k = 0; k < g.nbr; ++k) {  // x0 (nbr, B, Tp, fcrop); mag / cos / sin of the mask branch
+        br[k].wlen = g.wins[k];
+        br[k].x0 = x0 + (size_t)k * B * Tp * g.fcrop;
+        if (k == g.mask_br) { br[k].mag = mag; br[k].cosv = cos_out; br[k].sinv = sin_out; }
+    }
+    HIP_TRY(c, lass_launch_stft2(wav, B, L, g.nfft, LASS_HOP, T, Tp, g.nbr, br, g.magphase_sem, c->bn0_s, c->bn0_h,
+                                 c->tw2k, (hipStream_t)stream));
     return 0;
 }
 
@@ -876,6 +996,7 @@ int lass_workspace_tensor(const lass_ctx* c, int B, int L, const char* name_c, s
     if (!c || !name_c || !offset || !shape || !strides) return LASS_ERR_ARG;
     Plan pl;
     if (make_plan(c, B, L, &pl)) return LASS_ERR_ARG;
+    const Geometry& g = c->g;
     const std::string name(name_c);
     auto put = [&](size_t off, int64_t C, int64_t H, int64_t W, int64_t bs) {
         *offset = off;
@@ -883,26 +1004,31 @@ int lass_workspace_tensor(const lass_ctx* c, int B, int L, const char* name_c, s
         strides[0] = bs; strides[1] = H * W; strides[2] = W; strides[3] = 1;
         return 0;
     };
-    const int64_t spec = (int64_t)pl.T * LASS_NBINS;
-    if (name == "mag") return put(pl.mag, 1, pl.T, LASS_NBINS, spec);
-    if (name == "cos") return put(pl.cosv, 1, pl.T, LASS_NBINS, spec);
-    if (name == "sin") return put(pl.sinv, 1, pl.T, LASS_NBINS, spec);
-    if (name == "out_real") return put(pl.oreal, 1, pl.T, LASS_NBINS, spec);
-    if (name == "out_imag") return put(pl.oimag, 1, pl.T, LASS_NBINS, spec);
-    if (name == "x0") return put(pl.x0, 1, pl.Tp, LASS_FCROP, (int64_t)pl.Tp * LASS_FCROP);
+    const int64_t spec = (int64_t)pl.T * g.nbins;
+    if (name == "mag") return put(pl.mag, 1, pl.T, g.nbins, spec);
+    if (name == "cos") return put(pl.cosv, 1, pl.T, g.nbins, spec);
+    if (name == "sin") return put(pl.sinv, 1, pl.T, g.nbins, spec);
+    if (name == "out_real") return put(pl.oreal, 1, pl.T, g.nbins, spec);
+    if (name == "out_imag") return put(pl.oimag, 1, pl.T, g.nbins, spec);
+    for (int k = 0; k < g.nbr; ++k)
+        if (name == (g.variant == 0 ? std::string("x0") : "x0." + std::to_string(g.wins[k])))
+            return put(pl.x0[k], 1, pl.Tp, g.fcrop, (int64_t)pl.Tp * g.fcrop);
     for (int i = 0; i < 7; ++i) {
-        const int64_t H = pl.eh[i], W = pl.ew[i], C = kEnc[i].cout;
-        if (name == kEnc[i].name) {
+        const EncSpec& e = c->E[i];
+        const int64_t H = pl.eh[i], W = pl.ew[i];
+        const int64_t C = (int64_t)e.cout * (i == 0 ? g.nbr : 1);  // encoder_block1: all branches, channel-concatenated
+        if (name == e.name) {
             if (i == 6) return put(pl.center, C, H, W, C * H * W);
-            return put(pl.cat[5 - i] + (size_t)C * H * W * sizeof(float), C, H, W, 2 * C * H * W);  // skip half of the concat
+            const int d = 5 - i;  // the skip lives in place behind the transposed-conv half of decoder d's concat
+            return put(pl.cat[d] + (size_t)c->D[d].cout * H * W * sizeof(float), C, H, W, (int64_t)c->dec_cat[d] * H * W);
         }
-        if (i < 6 && name == std::string(kEnc[i].name) + ".pool")
-            return put(pl.pool[i], C, H / kEnc[i].dh, W / kEnc[i].dw, C * (H / kEnc[i].dh) * (W / kEnc[i].dw));
+        if (i < 6 && name == std::string(e.name) + ".pool")
+            return put(pl.pool[i], C, H / e.dh, W / e.dw, C * (H / e.dh) * (W / e.dw));
     }
     for (int d = 0; d < 6; ++d) {
-        const int64_t H = pl.eh[5 - d], W = pl.ew[5 - d], C = kDec[d].cout;
-        if (name == std::string(kDec[d].name) + ".up") return put(pl.cat[d], C, H, W, 2 * C * H * W);
-        if (name == kDec[d].name) return put(pl.decout[d], C, H, W, C * H * W);
+        const int64_t H = pl.eh[5 - d], W = pl.ew[5 - d], C = c->D[d].cout;
+        if (name == std::string(c->D[d].name) + ".up") return put(pl.cat[d], C, H, W, (int64_t)c->dec_cat[d] * H * W);
+        if (name == c->D[d].name) return put(pl.decout[d], C, H, W, C * H * W);
     }
     return LASS_ERR_ARG;
 }
@@ -913,8 +1039,8 @@ int lass_upconv(lass_ctx* c, const char* name, const float* x, int B, int h, int
     if (r) return r;
     if (!name || !x || !shift || !y) return fail(c, LASS_ERR_ARG, "lass_upconv: bad argument");
     for (int i = 0; i < 6; ++i)
-        if (std::string("base.") + kDec[i].name == name)
-            return run_upconv(c, i, x, B, h, w, shift, y, (long)kDec[i].cout * h * kDec[i].uh * w * kDec[i].uw,
+        if (std::string("base.") + c->D[i].name == name)
+            return run_upconv(c, i, x, B, h, w, shift, y, (long)c->D[i].cout * h * c->D[i].uh * w * c->D[i].uw,
                               (hipStream_t)stream);
     return fail(c, LASS_ERR_ARG, std::string("lass_upconv: unknown decoder '") + name + "'");
 }
@@ -926,7 +1052,7 @@ int lass_mask_apply(lass_ctx* c, const float* x12, const float* mag, const float
     if (!x12 || !mag || !cos_in || !sin_in || !out_real || !out_imag)
         return fail(c, LASS_ERR_ARG, "lass_mask_apply: bad argument");
     HIP_TRY(c, lass_launch_mask(x12, rawp(c, "base.after_conv.weight"), rawp(c, "base.after_conv.bias"), mag, cos_in,
-                                sin_in, B, T, Tpad, out_real, out_imag, (hipStream_t)stream));
+                                sin_in, B, T, Tpad, c->g.fcrop, out_real, out_imag, (hipStream_t)stream));
     return 0;
 }
 
@@ -946,52 +1072,77 @@ int lass_mix_at_snr(lass_ctx* c, float* source, const float* noise, const float*
     return 0;
 }
 
-int lass_separate(lass_ctx* c, const float* mixture, const float* condition, float* out, int B, int L, void* workspace,
-                  size_t workspace_bytes, void* stream) {
+// Precomputed analysis of the mixtures (the reference's multi-STFT wrapper reads these from input_dict,
+// resunet_with_multistft.py:233-241): magnitude per branch, cos / sin of the mask branch, each (B, T, nbins).
+struct Components {
+    const float* mag[kMaxBranches];
+    const float* cosv;
+    const float* sinv;
+};
+
+static int separate_impl(lass_ctx* c, const float* mixture, const Components* comp, const float* condition, float* out,
+                         int B, int L, void* workspace, size_t workspace_bytes, void* stream, const char* who) {
     int r = check_ready(c);
     if (r) return r;
-    if (!mixture || !condition || !out || !workspace) return fail(c, LASS_ERR_ARG, "lass_separate: null pointer");
+    const Geometry& g = c->g;
+    if ((!mixture && !comp) || !condition || !out || !workspace) return fail(c, LASS_ERR_ARG, std::string(who) + ": null pointer");
     Plan pl;
     if (make_plan(c, B, L, &pl))
-        return fail(c, LASS_ERR_ARG, "lass_separate: need B >= 1 and 512 < L <= " + std::to_string(kMaxSamples) +
-                                         " samples per clip (longer clips: ResUNet30.chunk_inference)");
+        return fail(c, LASS_ERR_ARG, std::string(who) + ": need B >= 1 and " + std::to_string(g.nfft / 2) +
+                                         " < L, with decoder_block6's concat (" + std::to_string(c->dec_cat[5]) +
+                                         " ch x frames x " + std::to_string(g.fcrop) + " bins, f32) below " +
+                                         ((c->compute_mode == LASS_COMPUTE_F32 && c->wino) ? "4" : "2") +
+                                         " GiB per clip (longer clips: ResUNet30.chunk_inference)");
     if (workspace_bytes < pl.total)
         return fail(c, LASS_ERR_WORKSPACE, "workspace too small: need " + std::to_string(pl.total) + " bytes");
     if (((uintptr_t)workspace & 255) != 0) return fail(c, LASS_ERR_ARG, "workspace must be 256-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     char* ws = (char*)workspace;
     auto F = [&](size_t off) { return (float*)(ws + off); };
-    const int T = pl.T, Tp = pl.Tp;
+    const int T = pl.T, Tp = pl.Tp, nbr = g.nbr;
     float* shift = F(pl.shift);
-    {
+    // ---- front end: STFT + magnitude / phase + bn0 / T-pad / F-crop (base.py:83-113, resunet.py:533-552) ------------
+    const float *mag_m = F(pl.mag), *cos_m = F(pl.cosv), *sin_m = F(pl.sinv);  // of the mask branch
+    if (mixture) {
         ProfScope ps(c, st, P_STFT);
-        HIP_TRY(c, lass_launch_stft(mixture, B, L, T, Tp, c->tw, c->win, F(pl.mag), F(pl.cosv), F(pl.sinv), nullptr,
-                                    nullptr, F(pl.x0), c->bn0_s, c->bn0_h, st));
+        StftBranch br[kMaxBranches];
+        for (int k = 0; k < nbr; ++k) {
+            br[k].wlen = g.wins[k];
+            br[k].x0 = F(pl.x0[k]);
+            if (k == g.mask_br) { br[k].mag = F(pl.mag); br[k].cosv = F(pl.cosv); br[k].sinv = F(pl.sinv); }
+        }
+        HIP_TRY(c, lass_launch_stft2(mixture, B, L, g.nfft, LASS_HOP, T, Tp, nbr, br, g.magphase_sem, c->bn0_s, c->bn0_h,
+                                     c->tw2k, st));
+    } else {
+        ProfScope ps(c, st, P_STFT);
+        for (int k = 0; k < nbr; ++k) {
+            if (!comp->mag[k]) return fail(c, LASS_ERR_ARG, std::string(who) + ": null magnitude");
+            HIP_TRY(c, lass_launch_x0_from_mag(comp->mag[k], B, T, Tp, g.fcrop, c->bn0_s, c->bn0_h, F(pl.x0[k]), st));
+        }
+        if (!comp->cosv || !comp->sinv) return fail(c, LASS_ERR_ARG, std::string(who) + ": null phase");
+        mag_m = comp->mag[g.mask_br]; cos_m = comp->cosv; sin_m = comp->sinv;
     }
     {
         ProfScope ps(c, st, P_FILM);
         HIP_TRY(c, lass_launch_film(condition, B, c->film_W, c->film_b, c->bn_base, c->n_shift, shift, st));
     }
     // pre_conv (resunet.py:555) is normally never materialised: encoder_block1 forms it from x0 while staging
-    const bool fuse_pre = c->fuse_preconv;
-    if (!fuse_pre) {
-        ProfScope ps(c, st, P_PRECONV);
-        HIP_TRY(c, lass_launch_preconv(F(pl.x0), rawp(c, "base.pre_conv.weight"), rawp(c, "base.pre_conv.bias"), B,
-                                       kPreCh, (long)Tp * LASS_FCROP, F(pl.xpre), st));
-    }
-    // bf16 mode: decoders 2-6 (2x2 up-sampling) take their concat as blocked bf16 copies written by the producers
+    const bool fuse_pre = c->fuse_preconv || nbr > 1;
+    // bf16 mode (ResUNet30 only): decoders 2-6 (2x2 up-sampling) take their concat as blocked bf16 copies written by the
+    // producers
     CatCopies cb[6];
     bool use_cb[6] = {false, false, false, false, false, false};
     for (int d = 1; d < 6; ++d) {
         const int e = 5 - d;
         const ResBlock& rd = c->dec[d];
+        const ResBlock& re = c->enc[nbr - 1 + e];
         const long hw = (long)pl.eh[e] * pl.ew[e];
-        use_cb[d] = c->fuse_catb && c->compute_mode == LASS_COMPUTE_BF16 && kDec[d].uh == 2 && kDec[d].uw == 2 && c->fuse_pool &&
-                    (pl.eh[e] % kEnc[e].dh) == 0 && rd.cout % 16 == 0 && rd.b1 && rd.b2 && rd.bsc16 && c->up16[d] &&
-                    c->enc[e].b1 && c->enc[e].b2 && (e != 0 || fuse_pre);
+        use_cb[d] = g.variant == 0 && c->fuse_catb && c->compute_mode == LASS_COMPUTE_BF16 && c->D[d].uh == 2 && c->D[d].uw == 2 &&
+                    c->fuse_pool && (pl.eh[e] % c->E[e].dh) == 0 && rd.cout % 16 == 0 && rd.b1 && rd.b2 && rd.bsc16 &&
+                    c->up16[d] && re.b1 && re.b2 && (e != 0 || fuse_pre);
         cb[d].act = F(pl.cat[d]);
-        cb[d].raw = (char*)F(pl.cat[d]) + (size_t)B * 2 * rd.cout * hw * 2;
-        cb[d].noct = 2 * rd.cout / 8;
+        cb[d].raw = (char*)F(pl.cat[d]) + (size_t)B * rd.cin * hw * 2;
+        cb[d].noct = rd.cin / 8;
         cb[d].scale = c->bn_scale + c->sites[rd.s1].off;
         cb[d].shift = shift + c->sites[rd.s1].off;
     }
@@ -999,9 +1150,9 @@ int lass_separate(lass_ctx* c, const float* mixture, const float* condition, flo
     CatCopies pc[4];
     bool use_pc[4] = {false, false, false, false};
     for (int i = 0; i < 4; ++i) {
-        const ResBlock& nx = c->enc[i + 1];
+        const ResBlock& nx = c->enc[nbr - 1 + i + 1];
         const long hwo = (long)pl.eh[i + 1] * pl.ew[i + 1];
-        use_pc[i] = c->fuse_catb && c->compute_mode == LASS_COMPUTE_BF16 && c->fuse_pool && kEnc[i].dh == 2 &&
+        use_pc[i] = g.variant == 0 && c->fuse_catb && c->compute_mode == LASS_COMPUTE_BF16 && c->fuse_pool && c->E[i].dh == 2 &&
                     (pl.eh[i] % 2) == 0 && pl.ew[i] % 32 == 0 && (i != 0 || fuse_pre) && use_cb[5 - i] && use_cb[5 - (i + 1)] &&
                     nx.cin != nx.cout && nx.cin % 16 == 0 && nx.b1 && nx.b2 && nx.bsc16;
         pc[i].act = F(pl.pool[i]);
@@ -1010,39 +1161,55 @@ int lass_separate(lass_ctx* c, const float* mixture, const float* condition, flo
         pc[i].scale = c->bn_scale + c->sites[nx.s1].off;
         pc[i].shift = shift + c->sites[nx.s1].off;
     }
-    // ---- encoder (resunet.py:556-562) -------------------------------------------------------------------------
-    const float* x = F(pl.xpre);
+    // ---- encoder (resunet.py:556-562; resunet_with_multistft.py:151-179) -----------------------------------------------
+    const float* x = nullptr;
     for (int i = 0; i < 7; ++i) {
         const int H = pl.eh[i], W = pl.ew[i];
         const long HW = (long)H * W;
-        const ResBlock& rb = c->enc[i];
-        float* o;
-        long o_bs;
-        if (i < 6) {  // skip output lives in the second channel half of decoder (5-i)'s concat buffer
-            o = F(pl.cat[5 - i]) + (size_t)rb.cout * HW;
-            o_bs = 2 * rb.cout * HW;
-        } else {
-            o = F(pl.center);
-            o_bs = rb.cout * HW;
-        }
-        // F.avg_pool2d (resunet.py:197) is fused into conv2's epilogue; W >= 16 at every pooled level
-        const bool fuse_pool = i < 6 && c->fuse_pool && (H % kEnc[i].dh) == 0;
-        r = run_resblock(c, rb, x, rb.cin * HW, B, H, W, shift, F(pl.a2), o, o_bs, st,
-                         fuse_pool ? F(pl.pool[i]) : nullptr, kEnc[i].dh,
-                         (i == 0 && fuse_pre) ? F(pl.x0) : nullptr, nullptr,
-                         (i < 5 && use_cb[5 - i]) ? &cb[5 - i] : nullptr,
-                         (i >= 1 && i <= 4 && use_pc[i - 1]) ? &pc[i - 1] : nullptr, nullptr,
-                         (i < 4 && use_pc[i]) ? &pc[i] : nullptr);
-        if (r) return r;
-        if (i < 6) {
-            if (!fuse_pool) {
-                ProfScope ps(c, st, P_POOL);
-                HIP_TRY(c, lass_launch_pool(o, o_bs, B, rb.cout, H, W, kEnc[i].dh, kEnc[i].dw, F(pl.pool[i]), st));
+        const EncSpec& e = c->E[i];
+        const int nb = i == 0 ? nbr : 1;  // encoder_block1 runs once per analysis branch
+        const bool fuse_pool = i < 6 && c->fuse_pool && (H % e.dh) == 0;
+        float* o = nullptr;
+        long o_bs = 0;
+        for (int k = 0; k < nb; ++k) {
+            const ResBlock& rb = c->enc[i == 0 ? k : nbr - 1 + i];
+            const int cofs = k * e.cout;  // channel offset of this branch inside the concatenated skip / pool
+            if (i < 6) {  // skip output lives behind the transposed-conv half of decoder (5-i)'s concat buffer
+                const int d = 5 - i;
+                o = F(pl.cat[d]) + (size_t)(c->D[d].cout + cofs) * HW;
+                o_bs = (long)c->dec_cat[d] * HW;
+            } else {
+                o = F(pl.center);
+                o_bs = rb.cout * HW;
             }
-            x = F(pl.pool[i]);
-        } else {
-            x = o;  // downsample (1,1) is the identity (resunet.py:363-370)
+            const long Ho = H / e.dh, Wo = W / e.dw;
+            float* pool_k = i < 6 ? F(pl.pool[i]) + (size_t)cofs * Ho * Wo : nullptr;
+            const long pool_bs = (long)e.cout * nb * Ho * Wo;
+            PreConv pre{nullptr, nullptr, nullptr};
+            const float* xin = x;
+            if (i == 0) {
+                if (fuse_pre) {
+                    pre = PreConv{F(pl.x0[k]), rawp(c, c->pre_name[k] + ".weight"), rawp(c, c->pre_name[k] + ".bias")};
+                } else {
+                    ProfScope ps(c, st, P_PRECONV);
+                    HIP_TRY(c, lass_launch_preconv(F(pl.x0[k]), rawp(c, c->pre_name[k] + ".weight"),
+                                                   rawp(c, c->pre_name[k] + ".bias"), B, kPreCh, HW, F(pl.xpre), st));
+                    xin = F(pl.xpre);
+                }
+            }
+            // F.avg_pool2d (resunet.py:197) is fused into conv2's epilogue; W >= 16 at every pooled level
+            r = run_resblock(c, rb, xin, rb.cin * HW, B, H, W, shift, F(pl.a2), o, o_bs, st, fuse_pool ? pool_k : nullptr,
+                             e.dh, pre.x0 ? &pre : nullptr, nullptr, (i < 5 && use_cb[5 - i]) ? &cb[5 - i] : nullptr,
+                             (i >= 1 && i <= 4 && use_pc[i - 1]) ? &pc[i - 1] : nullptr, nullptr,
+                             (i < 4 && use_pc[i]) ? &pc[i] : nullptr, pool_bs);
+            if (r) return r;
+            if (i < 6 && !fuse_pool) {
+                ProfScope ps(c, st, P_POOL);
+                if (nb > 1) return fail(c, LASS_ERR_STATE, "the multi-STFT model needs the fused avg-pool (LASS_FUSE_POOL=1)");
+                HIP_TRY(c, lass_launch_pool(o, o_bs, B, rb.cout, H, W, e.dh, e.dw, F(pl.pool[i]), st));
+            }
         }
+        x = i < 6 ? F(pl.pool[i]) : o;  // conv_block7a: downsample (1,1) is the identity (resunet.py:363-370)
     }
     // ---- decoder (resunet.py:563-568) -------------------------------------------------------------------------
     bool x_act = false;  // x (input of the next transposed conv) is an activated blocked bf16 tensor
@@ -1051,35 +1218,51 @@ int lass_separate(lass_ctx* c, const float* mixture, const float* condition, flo
         const int e = 5 - d;
         const int H = pl.eh[e], W = pl.ew[e];
         const long HW = (long)H * W;
-        const int h = H / kDec[d].uh, w = W / kDec[d].uw;
+        const int h = H / c->D[d].uh, w = W / c->D[d].uw;
         const ResBlock& rb = c->dec[d];
-        r = run_upconv(c, d, x, B, h, w, shift, F(pl.cat[d]), 2 * rb.cout * HW, st, use_cb[d] ? &cb[d] : nullptr, x_act);
+        r = run_upconv(c, d, x, B, h, w, shift, F(pl.cat[d]), rb.cin * HW, st, use_cb[d] ? &cb[d] : nullptr, x_act);
         if (r) return r;
         // this decoder's output feeds only the next transposed conv: hand it over activated, as blocked bf16
-        const bool act_next = d < 5 && c->fuse_catb && c->compute_mode == LASS_COMPUTE_BF16 && rb.b1 && rb.b2 && rb.bsc16 &&
-                              rb.cout % 16 == 0 && c->up16[d + 1];
+        const bool act_next = g.variant == 0 && d < 5 && c->fuse_catb && c->compute_mode == LASS_COMPUTE_BF16 && rb.b1 && rb.b2 &&
+                              rb.bsc16 && rb.cout % 16 == 0 && c->up16[d + 1];
         x_act = act_next;
-        if (r) return r;
-        // decoder_block6 (32 channels at the full 512-bin resolution): after_conv + mask run in conv2's epilogue
-        const MaskHead head{F(pl.mag), F(pl.cosv), F(pl.sinv), F(pl.oreal), F(pl.oimag), T};
-        fused_head = d == 5 && c->fuse_mask && rb.cout == 32 && rb.cin != rb.cout && W == LASS_FCROP;
-        r = run_resblock(c, rb, F(pl.cat[d]), 2 * rb.cout * HW, B, H, W, shift, F(pl.a2), F(pl.decout[d]),
-                         rb.cout * HW, st, nullptr, 2, nullptr, fused_head ? &head : nullptr, nullptr,
-                         use_cb[d] ? &cb[d] : nullptr, act_next ? &c->sites[c->dec_site[d + 1]] : nullptr);
+        // decoder_block6 (32 channels at the full resolution): after_conv + mask run in conv2's epilogue
+        const MaskHead head{mag_m, cos_m, sin_m, F(pl.oreal), F(pl.oimag), T, g.nbins};
+        fused_head = d == 5 && c->fuse_mask && rb.cout == 32 && rb.cin != rb.cout && W == g.fcrop;
+        r = run_resblock(c, rb, F(pl.cat[d]), rb.cin * HW, B, H, W, shift, F(pl.a2), F(pl.decout[d]), rb.cout * HW, st,
+                         nullptr, 2, nullptr, fused_head ? &head : nullptr, nullptr, use_cb[d] ? &cb[d] : nullptr,
+                         act_next ? &c->sites[c->dec_site[d + 1]] : nullptr);
         if (r) return r;
         x = F(pl.decout[d]);
     }
     if (!fused_head) {
         ProfScope ps(c, st, P_MASK);
-        HIP_TRY(c, lass_launch_mask(x, rawp(c, "base.after_conv.weight"), rawp(c, "base.after_conv.bias"), F(pl.mag),
-                                    F(pl.cosv), F(pl.sinv), B, T, Tp, F(pl.oreal), F(pl.oimag), st));
+        HIP_TRY(c, lass_launch_mask(x, rawp(c, "base.after_conv.weight"), rawp(c, "base.after_conv.bias"), mag_m, cos_m,
+                                    sin_m, B, T, Tp, g.fcrop, F(pl.oreal), F(pl.oimag), st));
     }
     {
         ProfScope ps(c, st, P_ISTFT);
-        HIP_TRY(c, lass_launch_istft_frames(F(pl.oreal), F(pl.oimag), B, T, c->tw, c->win, F(pl.frames), st));
-        HIP_TRY(c, lass_launch_istft_ola(F(pl.frames), B, T, L, c->win, out, st));
+        HIP_TRY(c, lass_launch_istft2(F(pl.oreal), F(pl.oimag), B, T, L, g.nfft, g.wins[g.mask_br], LASS_HOP, c->tw2k, out, st));
     }
     return 0;
+}
+
+int lass_separate(lass_ctx* c, const float* mixture, const float* condition, float* out, int B, int L, void* workspace,
+                  size_t workspace_bytes, void* stream) {
+    if (!mixture) return fail(c, LASS_ERR_ARG, "lass_separate: null pointer");
+    return separate_impl(c, mixture, nullptr, condition, out, B, L, workspace, workspace_bytes, stream, "lass_separate");
+}
+
+int lass_separate_components(lass_ctx* c, const float* const* mag, const float* cos_mask, const float* sin_mask,
+                             const float* condition, float* out, int B, int L, void* workspace, size_t workspace_bytes,
+                             void* stream) {
+    if (!c) return LASS_ERR_ARG;
+    if (!mag || !cos_mask || !sin_mask) return fail(c, LASS_ERR_ARG, "lass_separate_components: null pointer");
+    Components comp;
+    for (int k = 0; k < kMaxBranches; ++k) comp.mag[k] = k < c->g.nbr ? mag[k] : nullptr;
+    comp.cosv = cos_mask; comp.sinv = sin_mask;
+    return separate_impl(c, nullptr, &comp, condition, out, B, L, workspace, workspace_bytes, stream,
+                         "lass_separate_components");
 }
 
 int lass_set_profiling(lass_ctx* c, int enabled) {

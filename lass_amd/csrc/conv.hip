@@ -633,7 +633,7 @@ hipError_t lass_launch_conv(ConvKind kind, const ConvArgs& p, hipStream_t stream
         case CONV2_SHORTCUT:  // 3x3 over pre-activated input, + 1x1(in2) + bias
             if (!conv_args_ok(p, 9, true) || !p.in2 || !p.w2 || !p.bias) return hipErrorInvalidValue;
             if (p.mask_re) {  // fused output head: decoder_block6 geometry only
-                if (p.N != 32 || p.W != LASS_FCROP || !p.mask_w || !p.mask_b || !p.mask_mag || !p.mask_cos || !p.mask_sin ||
+                if (p.N != 32 || p.W + 1 != p.mask_nbins || !p.mask_w || !p.mask_b || !p.mask_mag || !p.mask_cos || !p.mask_sin ||
                     !p.mask_im || p.mask_T <= 0 || p.mask_T > p.H)
                     return hipErrorInvalidValue;
                 return launch_one<9, 1, 2, 32, F_PHASEB | F_BIAS | F_MASK>(p, stream);

@@ -546,7 +546,7 @@ hipError_t lass_launch_conv_bf16(ConvKind kind, const ConvArgs& p, hipStream_t s
             if ((!p.in2 && !p.in2_bf16) || !p.w2_bf16 || !p.bias || p.Cin2 % 16 != 0 || (p.w_bf16_lo && !p.w2_bf16_lo))
                 return hipErrorInvalidValue;
             if (p.mask_re) {  // fused output head: decoder_block6 geometry only
-                if (p.N != 32 || p.W != LASS_FCROP || !p.in_bf16 || !p.mask_w || !p.mask_b || !p.mask_mag || !p.mask_cos ||
+                if (p.N != 32 || p.W + 1 != p.mask_nbins || !p.in_bf16 || !p.mask_w || !p.mask_b || !p.mask_mag || !p.mask_cos ||
                     !p.mask_sin || !p.mask_im || p.mask_T <= 0 || p.mask_T > p.H)
                     return hipErrorInvalidValue;
                 if (p.in2_bf16)

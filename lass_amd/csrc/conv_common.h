@@ -184,7 +184,7 @@ __device__ __forceinline__ void store_tile(const ConvArgs& p, f32x16 (&acc)[NCO]
                 if (PW == 32 && NPX == 2) {
                     const int y = y0 + wave * WROWS;  // even row of the pair (px-tile 0); px-tile 1 is y+1
                     const int Ho = p.H / 2;
-                    float* dst = p.pool_out + ((size_t)b * p.N + n0 + co * 32 + 4 * khalf) * Ho * Wo +
+                    float* dst = p.pool_out + (size_t)b * (p.pool_bs ? (size_t)p.pool_bs : (size_t)p.N * Ho * Wo) + (size_t)(n0 + co * 32 + 4 * khalf) * Ho * Wo +
                                  (size_t)(y >> 1) * Wo + (x >> 1);
                     float pooled[16];
 #pragma unroll
@@ -223,7 +223,7 @@ __device__ __forceinline__ void store_tile(const ConvArgs& p, f32x16 (&acc)[NCO]
 #pragma unroll
                 for (int px = 0; px < NPX; ++px) {
                     const int y = y0 + wave * WROWS + px * PH + ty;
-                    float* dst = p.pool_out + ((size_t)b * p.N + n0 + co * 32 + 4 * khalf) * p.H * Wo +
+                    float* dst = p.pool_out + (size_t)b * (p.pool_bs ? (size_t)p.pool_bs : (size_t)p.N * p.H * Wo) + (size_t)(n0 + co * 32 + 4 * khalf) * p.H * Wo +
                                  (size_t)min(y, p.H - 1) * Wo + (x >> 1);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {

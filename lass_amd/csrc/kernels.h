@@ -77,7 +77,10 @@ struct ConvArgs {
     float* mask_re = nullptr;         // (B, mask_T, 513) separated spectrum
     float* mask_im = nullptr;
     int mask_T = 0;                   // frames (rows y >= mask_T are the T padding: dropped)
-    float* pool_out = nullptr;  // fused avg-pool of the output: (B, N, H/pool_h, W/2) dense
+    int mask_nbins = LASS_NBINS;      // bins per spectrum row = W + 1 (513; 1025 for the multi-STFT model)
+    float* pool_out = nullptr;  // fused avg-pool of the output: (B, N, H/pool_h, W/2), batch stride pool_bs
+    long pool_bs = 0;            // elements between clips of pool_out; 0 = dense (N * H/pool_h * W/2).  A launch that
+                                 // produces a channel slice of a wider pooled tensor passes the wide tensor's stride.
     int pool_h = 2;              // vertical pool factor (1 or 2); horizontal is 2
     long long* dbg = nullptr;  // diagnostic builds (-DLASS_CONV_DIAG) only: 8 int64 per block
 };
@@ -99,22 +102,26 @@ hipError_t lass_launch_weights_bf16(const float* w, int Cout, int Cin, int taps,
                                     hipStream_t stream);
 
 // ---- stft.hip -----------------------------------------------------------------------------------------------------
-// tw: 1024 float2 (cos, sin)(2*pi*k/1024); win: 1024 floats (periodic Hann)
-// Writes mag/cos/sin/real/imag (B,T,513) where non-null and, when x0 != null, the bn0-normalised, T-padded, F-cropped
-// network input x0 (B,Tpad,512) = mag*s0[f] + h0[f] for t < T, 0 for T <= t < Tpad.
-hipError_t lass_launch_stft(const float* wav, int B, int L, int T, int Tpad, const float2* tw, const float* win,
-                            float* mag, float* cosv, float* sinv, float* real, float* imag, float* x0,
-                            const float* s0, const float* h0, hipStream_t stream);
 // Multi-resolution analysis (scripts/precompute_stfts.py:19-58,573-590): nwin centred STFTs (n_fft = win in {256, 512,
 // 1024, 2048}, periodic Hann, reflect pad, common hop) of the same waveforms in one launch, torchlibrosa-magphase
 // semantics (clamp on |X| at 1e-10).  Outputs (B, T, n_fft/2+1) each, T = 1 + L/hop.  tw2k: 2048 (cos, sin)(2*pi*k/2048).
 hipError_t lass_launch_multi_stft(const float* wav, int B, int L, int hop, int nwin, const int* n_fft,
                                   const float2* tw2k, float* const* mag, float* const* cosv, float* const* sinv,
                                   hipStream_t stream);
-hipError_t lass_launch_istft_frames(const float* real, const float* imag, int B, int T, const float2* tw,
-                                    const float* win, float* frames, hipStream_t stream);
-hipError_t lass_launch_istft_ola(const float* frames, int B, int T, int L, const float* win, float* wav,
-                                 hipStream_t stream);
+// Generic pair-packed transforms (stft.hip): n_fft in {1024, 2048}; each branch is a periodic Hann window of `wlen`
+// samples (a divisor of 2048, <= n_fft) zero-padded to n_fft and centred.  Outputs per branch where non-null:
+// mag/cos/sin/real/imag (B, T, n_fft/2+1) and x0 (B, Tpad, n_fft/2) = bn0(mag), zero rows T..Tpad-1, Nyquist dropped.
+// magphase_sem: 0 = base.py:83-88 (clamp on |X|^2), 1 = torchlibrosa magphase (clamp on |X|).
+struct StftBranch {
+    int wlen = 0;
+    float *mag = nullptr, *cosv = nullptr, *sinv = nullptr, *real = nullptr, *imag = nullptr, *x0 = nullptr;
+};
+hipError_t lass_launch_stft2(const float* wav, int B, int L, int n_fft, int hop, int T, int Tpad, int nbr,
+                             const StftBranch* br, int magphase_sem, const float* s0, const float* h0,
+                             const float2* tw2k, hipStream_t stream);
+// Fused inverse STFT (inverse transforms + overlap-add + envelope + trim in one kernel, no frame scratch).
+hipError_t lass_launch_istft2(const float* real, const float* imag, int B, int T, int L, int n_fft, int wlen, int hop,
+                              const float2* tw2k, float* wav, hipStream_t stream);
 
 // ---- misc.hip -----------------------------------------------------------------------------------------------------
 // film[b][j] = dot(cond[b], Wf[j]) + bf[j] (+ base[j] if base)   for j < n
@@ -127,8 +134,11 @@ hipError_t lass_launch_preconv(const float* x0, const float* w, const float* bia
 hipError_t lass_launch_pool(const float* in, long in_bs, int B, int C, int H, int W, int ph, int pw, float* out,
                             hipStream_t stream);
 hipError_t lass_launch_mask(const float* x12, const float* wa, const float* ba, const float* mag, const float* cosv,
-                            const float* sinv, int B, int T, int Tpad, float* out_real, float* out_imag,
+                            const float* sinv, int B, int T, int Tpad, int fcrop, float* out_real, float* out_imag,
                             hipStream_t stream);
+// x0 (B,Tpad,fcrop) = bn0 affine of a precomputed magnitude (B,T,fcrop+1), zero rows T..Tpad-1
+hipError_t lass_launch_x0_from_mag(const float* mag, int B, int T, int Tpad, int fcrop, const float* s0,
+                                   const float* h0, float* x0, hipStream_t stream);
 hipError_t lass_launch_sdr(const float* ref, const float* est, int B, int L, double* stats, hipStream_t stream);
 // mixture = source + noise * sqrt(P_source / 10^(snr/10) / P_noise); if max|mixture| > 1 both source and mixture are
 // scaled by 0.9/max (dcase_evaluator.py:77-89).  source is updated in place; ws: 4*B doubles of scratch.

@@ -83,18 +83,16 @@ __global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ in,
 __global__ __launch_bounds__(256) void mask_kernel(const float* __restrict__ x12, const float* __restrict__ wa,
                                                    const float* __restrict__ ba, const float* __restrict__ mag,
                                                    const float* __restrict__ cosv, const float* __restrict__ sinv,
-                                                   int T, int Tpad, float* __restrict__ out_real,
+                                                   int T, int Tpad, int fcrop, float* __restrict__ out_real,
                                                    float* __restrict__ out_imag) {
     __shared__ float sw[3 * 32 + 3];
     const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     if (tid < 99) sw[tid] = tid < 96 ? wa[tid] : ba[tid - 96];
     __syncthreads();
-    const size_t plane = (size_t)Tpad * LASS_FCROP;
-    const float* xb = x12 + (size_t)b * 32 * plane + (size_t)t * LASS_FCROP;
-    const size_t row = ((size_t)b * T + t) * LASS_NBINS;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int f = tid + 256 * h;
+    const size_t plane = (size_t)Tpad * fcrop;
+    const float* xb = x12 + (size_t)b * 32 * plane + (size_t)t * fcrop;
+    const size_t row = ((size_t)b * T + t) * (fcrop + 1);
+    for (int f = tid; f < fcrop; f += 256) {
         float l0 = sw[96], l1 = sw[97], l2 = sw[98];
 #pragma unroll 8
         for (int c = 0; c < 32; ++c) {
@@ -116,8 +114,8 @@ __global__ __launch_bounds__(256) void mask_kernel(const float* __restrict__ x12
         out_imag[row + f] = om * os;
     }
     if (tid == 0) {
-        out_real[row + 512] = 0.f;
-        out_imag[row + 512] = 0.f;
+        out_real[row + fcrop] = 0.f;
+        out_imag[row + fcrop] = 0.f;
     }
 }
 
@@ -277,7 +275,7 @@ hipError_t lass_launch_preconv(const float* x0, const float* w, const float* bia
 
 hipError_t lass_launch_pool(const float* in, long in_bs, int B, int C, int H, int W, int ph, int pw, float* out,
                             hipStream_t stream) {
-    if (B <= 0 || C <= 0 || pw != 2 || (ph != 1 && ph != 2) || (H % ph) != 0 || (W % 2) != 0)
+    if (B <= 0 || C <= 0 || pw != 2 || (ph != 1 && ph != 2) || H < ph || (W % 2) != 0)  // odd H: floor, as F.avg_pool2d
         return hipErrorInvalidValue;
     const int npix = (H / ph) * (W / 2);
     dim3 grid((npix + 255) / 256, C, B);
@@ -288,12 +286,30 @@ hipError_t lass_launch_pool(const float* in, long in_bs, int B, int C, int H, in
     return hipGetLastError();
 }
 
+// x0[b][t][f] = mag[b][t][f] * s0[f] + h0[f] for t < T, f < fcrop; 0 for T <= t < Tpad  (resunet.py:537-552 on a
+// precomputed magnitude (B, T, fcrop+1))
+__global__ __launch_bounds__(256) void x0_from_mag_kernel(const float* __restrict__ mag, int T, int Tpad, int fcrop,
+                                                          const float* __restrict__ s0, const float* __restrict__ h0,
+                                                          float* __restrict__ x0) {
+    const int t = blockIdx.x, b = blockIdx.y;
+    float* dst = x0 + ((size_t)b * Tpad + t) * fcrop;
+    const float* src = mag + ((size_t)b * T + t) * (fcrop + 1);
+    for (int f = threadIdx.x; f < fcrop; f += 256) dst[f] = t < T ? src[f] * s0[f] + h0[f] : 0.f;
+}
+
+hipError_t lass_launch_x0_from_mag(const float* mag, int B, int T, int Tpad, int fcrop, const float* s0,
+                                   const float* h0, float* x0, hipStream_t stream) {
+    if (B <= 0 || T <= 0 || Tpad < T || fcrop <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(x0_from_mag_kernel, dim3(Tpad, B), dim3(256), 0, stream, mag, T, Tpad, fcrop, s0, h0, x0);
+    return hipGetLastError();
+}
+
 hipError_t lass_launch_mask(const float* x12, const float* wa, const float* ba, const float* mag, const float* cosv,
-                            const float* sinv, int B, int T, int Tpad, float* out_real, float* out_imag,
+                            const float* sinv, int B, int T, int Tpad, int fcrop, float* out_real, float* out_imag,
                             hipStream_t stream) {
-    if (B <= 0 || T <= 0 || Tpad < T) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(mask_kernel, dim3(T, B), dim3(256), 0, stream, x12, wa, ba, mag, cosv, sinv, T, Tpad, out_real,
-                       out_imag);
+    if (B <= 0 || T <= 0 || Tpad < T || fcrop <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(mask_kernel, dim3(T, B), dim3(256), 0, stream, x12, wa, ba, mag, cosv, sinv, T, Tpad, fcrop,
+                       out_real, out_imag);
     return hipGetLastError();
 }
 

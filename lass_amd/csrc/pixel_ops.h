@@ -12,7 +12,7 @@ __device__ __forceinline__ float leaky(float v) { return fmaxf(v, 0.01f * v); } 
 // The complex ratio mask of one time-frequency bin from its three after_conv logits (resunet.py:476-507; torchlibrosa
 // magphase clamps |M| at 1e-10); bin 512 is the zero padding of resunet.py:573, whose output is exactly 0.
 __device__ __forceinline__ void mask_pixel(const ConvArgs& p, int b, int t, int f, float l0, float l1, float l2) {
-    const size_t row = ((size_t)b * p.mask_T + t) * LASS_NBINS + f;
+    const size_t row = ((size_t)b * p.mask_T + t) * p.mask_nbins + f;
     const float mask_mag = 1.f / (1.f + expf(-l0));
     const float mr = tanhf(l1), mi = tanhf(l2);
     const float mm = sqrtf(mr * mr + mi * mi);
@@ -24,7 +24,7 @@ __device__ __forceinline__ void mask_pixel(const ConvArgs& p, int b, int t, int 
     const float om = fmaxf(p.mask_mag[row] * mask_mag, 0.f);
     p.mask_re[row] = om * oc;
     p.mask_im[row] = om * os;
-    if (f == LASS_FCROP - 1) {
+    if (f == p.mask_nbins - 2) {  // last kept bin: also write the dropped Nyquist bin's exact zero
         p.mask_re[row + 1] = 0.f;
         p.mask_im[row + 1] = 0.f;
     }

@@ -2,11 +2,12 @@
 //
 // Replaces (reference: /root/reference):
 //   torchlibrosa STFT.forward  (call: models/base.py:84; cfg: models/resunet.py:284-292) - there a Conv1d against a
-//       513x1024 windowed DFT matrix (1.05 GMAC/clip); here a 1024-point radix-4 Stockham FFT in LDS per frame.
+//       513x1024 windowed DFT matrix (1.05 GMAC/clip); here a radix-4 Stockham FFT in LDS, two real frames per complex
+//       transform (n_fft 1024, or 2048 with zero-padded windows for the multi-STFT model).
 //   Base.spectrogram_phase     (models/base.py:83-88, eps :91)
 //   bn0 / T-pad / F-crop       (models/resunet.py:537-552)
 //   torchlibrosa ISTFT.forward (call: models/resunet.py:510) - Hermitian extension, inverse DFT x Hann, overlap-add,
-//       division by the window-sum-square envelope, trim.
+//       division by the window-sum-square envelope, trim: one fused kernel, overlap-add in LDS, no frame scratch.
 // All of it is HBM-bound streaming: frames are read as contiguous 4-KB runs of the waveform, spectra are written as
 // contiguous 513-float rows.
 #include <hip/hip_runtime.h>
@@ -22,76 +23,6 @@ template <bool INV>
 __device__ __forceinline__ float2 ctw(float2 u, float2 w) {
     if (INV) return make_float2(u.x * w.x - u.y * w.y, u.y * w.x + u.x * w.y);
     return make_float2(u.x * w.x + u.y * w.y, u.y * w.x - u.x * w.y);
-}
-
-// 1024-point complex FFT, radix-4 Stockham autosort, 256 threads x 5 passes.  Input in `a`, output (natural order)
-// in `b`.  tw[k] = (cos, sin)(2*pi*k/1024) in LDS.  Ends with a barrier.
-template <bool INV>
-__device__ __forceinline__ void fft1024(float2* a, float2* b, const float2* tw, int tid) {
-    float2* src = a;
-    float2* dst = b;
-#pragma unroll
-    for (int pass = 0; pass < 5; ++pass) {
-        const int p = 1 << (2 * pass);
-        const int k = tid & (p - 1);
-        const int j = ((tid - k) << 2) + k;
-        const int ts = 256 >> (2 * pass);
-        float2 u0 = src[tid], u1 = src[tid + 256], u2 = src[tid + 512], u3 = src[tid + 768];
-        if (pass > 0) {
-            u1 = ctw<INV>(u1, tw[k * ts]);
-            u2 = ctw<INV>(u2, tw[2 * k * ts]);
-            u3 = ctw<INV>(u3, tw[3 * k * ts]);
-        }
-        const float2 a0 = cadd(u0, u2), a1 = csub(u0, u2), a2 = cadd(u1, u3);
-        float2 a3 = csub(u1, u3);
-        a3 = INV ? make_float2(-a3.y, a3.x) : make_float2(a3.y, -a3.x);  // * (+i) inverse, * (-i) forward
-        dst[j] = cadd(a0, a2);
-        dst[j + p] = cadd(a1, a3);
-        dst[j + 2 * p] = csub(a0, a2);
-        dst[j + 3 * p] = csub(a1, a3);
-        __syncthreads();
-        float2* t = src;
-        src = dst;
-        dst = t;
-    }
-}
-
-__global__ __launch_bounds__(256) void stft_kernel(const float* __restrict__ wav, int L, int T, int Tpad,
-                                                   const float2* __restrict__ tw, const float* __restrict__ win,
-                                                   float* __restrict__ mag, float* __restrict__ cosv,
-                                                   float* __restrict__ sinv, float* __restrict__ real,
-                                                   float* __restrict__ imag, float* __restrict__ x0,
-                                                   const float* __restrict__ s0, const float* __restrict__ h0) {
-    __shared__ float2 A[1024], Bf[1024], TW[1024];
-    const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-    if (t >= T) {  // rows T..Tpad-1 of the network input are zeros AFTER bn0 (resunet.py:537-548)
-        if (x0)
-            for (int f = tid; f < LASS_FCROP; f += 256) x0[((size_t)b * Tpad + t) * LASS_FCROP + f] = 0.f;
-        return;
-    }
-    const float* w = wav + (size_t)b * L;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int idx = tid + 256 * i;
-        TW[idx] = tw[idx];
-        int n = t * LASS_HOP + idx - LASS_NFFT / 2;  // centre=True, reflect padding of n_fft/2
-        if (n < 0) n = -n;
-        if (n >= L) n = 2 * (L - 1) - n;
-        A[idx] = make_float2(w[n] * win[idx], 0.f);
-    }
-    __syncthreads();
-    fft1024<false>(A, Bf, TW, tid);
-    const size_t row = ((size_t)b * T + t) * LASS_NBINS;
-    for (int f = tid; f < LASS_NBINS; f += 256) {
-        const float re = Bf[f].x, im = Bf[f].y;
-        const float m = sqrtf(fmaxf(re * re + im * im, 1e-10f));  // clamp on |X|^2 (base.py:85)
-        if (real) real[row + f] = re;
-        if (imag) imag[row + f] = im;
-        if (mag) mag[row + f] = m;
-        if (cosv) cosv[row + f] = re / m;
-        if (sinv) sinv[row + f] = im / m;
-        if (x0 && f < LASS_FCROP) x0[((size_t)b * Tpad + t) * LASS_FCROP + f] = m * s0[f] + h0[f];
-    }
 }
 
 // N-point complex forward FFT for N in {256, 512, 1024, 2048}: radix-4 Stockham passes plus one radix-2 pass when log2 N
@@ -190,81 +121,200 @@ __global__ __launch_bounds__(256) void multi_stft_kernel(const float* __restrict
     }
 }
 
-__global__ __launch_bounds__(256) void istft_frames_kernel(const float* __restrict__ real,
-                                                           const float* __restrict__ imag, int T,
-                                                           const float2* __restrict__ tw,
-                                                           const float* __restrict__ win,
-                                                           float* __restrict__ frames) {
-    __shared__ float2 A[1024], Bf[1024], TW[1024];
-    const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-    const size_t row = ((size_t)b * T + t) * LASS_NBINS;
+// ---- generic pair-packed transforms (n_fft in {1024, 2048}, window length <= n_fft) ---------------------------------
+// A real frame needs only half a complex transform: two frames ride in one complex FFT (frame a in the real part, frame b
+// in the imaginary part) and are separated by the Hermitian symmetry of their spectra:
+//     Z = FFT(xa + i xb):   Xa[k] = (Z[k] + conj(Z[N-k])) / 2,   Xb[k] = (Z[k] - conj(Z[N-k])) / (2i)
+// and the other way round for the inverse.  Twiddles and the periodic Hann window come from the 2048-entry table.
+template <int N, bool INV>
+__device__ __forceinline__ float2* fft_c(float2* a, float2* b, const float2* tw2k, int tid) {
+    constexpr int LOG2 = N == 1024 ? 10 : 11;
+    constexpr int NP4 = LOG2 / 2;
+    constexpr int TWS = 2048 / N;
+    float2* src = a;
+    float2* dst = b;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int k = tid + 256 * i;
-        TW[k] = tw[k];
-        // Hermitian extension 513 -> 1024 bins: Z[1024-k] = conj(Z[k])
-        A[k] = (k <= 512) ? make_float2(real[row + k], imag[row + k])
-                          : make_float2(real[row + 1024 - k], -imag[row + 1024 - k]);
-    }
-    __syncthreads();
-    fft1024<true>(A, Bf, TW, tid);
-    float* fr = frames + ((size_t)b * T + t) * LASS_NFFT;
+    for (int pass = 0; pass < NP4; ++pass) {
+        const int p = 1 << (2 * pass);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int n = tid + 256 * i;
-        fr[n] = Bf[n].x * (win[n] * (1.0f / LASS_NFFT));
+        for (int i = tid; i < N / 4; i += 256) {
+            const int k = i & (p - 1);
+            const int j = ((i - k) << 2) + k;
+            const int ts = (N / 4 / p) * TWS;
+            float2 u0 = src[i], u1 = src[i + N / 4], u2 = src[i + N / 2], u3 = src[i + 3 * N / 4];
+            if (pass > 0) {
+                u1 = ctw<INV>(u1, tw2k[k * ts]);
+                u2 = ctw<INV>(u2, tw2k[2 * k * ts]);
+                u3 = ctw<INV>(u3, tw2k[3 * k * ts]);
+            }
+            const float2 a0 = cadd(u0, u2), a1 = csub(u0, u2), a2 = cadd(u1, u3);
+            float2 a3 = csub(u1, u3);
+            a3 = INV ? make_float2(-a3.y, a3.x) : make_float2(a3.y, -a3.x);  // * (+i) inverse, * (-i) forward
+            dst[j] = cadd(a0, a2);
+            dst[j + p] = cadd(a1, a3);
+            dst[j + 2 * p] = csub(a0, a2);
+            dst[j + 3 * p] = csub(a1, a3);
+        }
+        __syncthreads();
+        float2* t = src; src = dst; dst = t;
     }
+    if (LOG2 & 1) {  // final radix-2 pass, p = N/2
+#pragma unroll
+        for (int i = tid; i < N / 2; i += 256) {
+            const float2 u0 = src[i];
+            const float2 u1 = ctw<INV>(src[i + N / 2], tw2k[i * TWS]);
+            dst[i] = cadd(u0, u1);
+            dst[i + N / 2] = csub(u0, u1);
+        }
+        __syncthreads();
+        float2* t = src; src = dst; dst = t;
+    }
+    return src;  // natural order
 }
 
-// Gather-form overlap-add: each output sample sums the <= 7 frames that cover it and divides by the window
-// sum-square envelope of the same frames (clamped at 1e-11), trimmed to [n_fft/2, n_fft/2 + L).
-__global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict__ frames, int T, int L,
-                                                        const float* __restrict__ win, float* __restrict__ wav) {
-    const int b = blockIdx.y;
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= L) return;
-    const int m = n + LASS_NFFT / 2;
-    int t_hi = m / LASS_HOP;
-    if (t_hi > T - 1) t_hi = T - 1;
-    int t_lo = (m - (LASS_NFFT - 1) + LASS_HOP - 1) / LASS_HOP;
-    if (m - (LASS_NFFT - 1) <= 0) t_lo = 0;
-    float acc = 0.f, env = 0.f;
-    const float* fb = frames + (size_t)b * T * LASS_NFFT;
-    for (int t = t_lo; t <= t_hi; ++t) {
-        const int off = m - t * LASS_HOP;
-        acc += fb[(size_t)t * LASS_NFFT + off];
-        const float wv = win[off];
-        env += wv * wv;
+struct Stft2Args {
+    int nbr;
+    int wlen[LASS_MAX_STFT_WINDOWS];
+    float* mag[LASS_MAX_STFT_WINDOWS];
+    float* cosv[LASS_MAX_STFT_WINDOWS];
+    float* sinv[LASS_MAX_STFT_WINDOWS];
+    float* real[LASS_MAX_STFT_WINDOWS];
+    float* imag[LASS_MAX_STFT_WINDOWS];
+    float* x0[LASS_MAX_STFT_WINDOWS];
+};
+
+// Centred, reflect-padded STFT of frames (2*blockIdx.x, 2*blockIdx.x + 1) of clip blockIdx.y for branch blockIdx.z
+// (periodic Hann of wlen samples zero-padded to N, centred), fused with magnitude / phase and the network-input prologue
+// x0 = bn0(mag) with T zero-padded to Tpad and the Nyquist bin dropped (resunet.py:533-552).
+// MAGPHASE: torchlibrosa magphase (clamp on |X|, precompute_stfts.py:51) instead of base.py:83-88 (clamp on |X|^2).
+template <int N, bool MAGPHASE>
+__global__ __launch_bounds__(256) void stft2_kernel(const float* __restrict__ wav, int L, int hop, int T, int Tpad,
+                                                    const float2* __restrict__ tw2k, Stft2Args a,
+                                                    const float* __restrict__ s0, const float* __restrict__ h0) {
+    __shared__ float2 A[N], Bf[N], TW[2048];
+    constexpr int NB = N / 2 + 1, FC = N / 2;
+    const int ta = 2 * blockIdx.x, b = blockIdx.y, z = blockIdx.z, tid = threadIdx.x;
+    float* x0 = a.x0[z];
+    if (ta >= T) {  // rows T..Tpad-1 of the network input are zeros AFTER bn0
+        if (x0)
+            for (int r = 0; r < 2; ++r)
+                if (ta + r < Tpad)
+                    for (int f = tid; f < FC; f += 256) x0[((size_t)b * Tpad + ta + r) * FC + f] = 0.f;
+        return;
     }
-    wav[(size_t)b * L + n] = acc / fmaxf(env, 1e-11f);
+    for (int i = tid; i < 2048; i += 256) TW[i] = tw2k[i];
+    __syncthreads();
+    const int wlen = a.wlen[z], woff = (N - wlen) / 2, wstride = 2048 / wlen;
+    const float* w = wav + (size_t)b * L;
+    const bool have_b = ta + 1 < T;
+    for (int idx = tid; idx < N; idx += 256) {
+        float2 v = make_float2(0.f, 0.f);
+        const int j = idx - woff;
+        if (j >= 0 && j < wlen) {
+            const float wn = 0.5f - 0.5f * TW[j * wstride].x;  // periodic Hann of wlen
+            int n = ta * hop + idx - N / 2;                     // centre=True, reflect padding of n_fft/2
+            int n2 = n + hop;
+            if (n < 0) n = -n;
+            if (n >= L) n = 2 * (L - 1) - n;
+            if (n2 < 0) n2 = -n2;
+            if (n2 >= L) n2 = 2 * (L - 1) - n2;
+            v = make_float2(w[n] * wn, have_b ? w[n2] * wn : 0.f);
+        }
+        A[idx] = v;
+    }
+    __syncthreads();
+    const float2* Z = fft_c<N, false>(A, Bf, TW, tid);
+    float *mag = a.mag[z], *cosv = a.cosv[z], *sinv = a.sinv[z], *real = a.real[z], *imag = a.imag[z];
+    for (int f = tid; f < NB; f += 256) {
+        const float2 z1 = Z[f], z2 = Z[(N - f) & (N - 1)];
+        const float re[2] = {0.5f * (z1.x + z2.x), 0.5f * (z1.y + z2.y)};
+        const float im[2] = {0.5f * (z1.y - z2.y), -0.5f * (z1.x - z2.x)};
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            if (r == 1 && !have_b) break;
+            const size_t row = ((size_t)b * T + ta + r) * NB + f;
+            float m, c, s;
+            if (MAGPHASE) {
+                m = sqrtf(re[r] * re[r] + im[r] * im[r]);
+                const float den = fmaxf(m, 1e-10f);
+                c = re[r] / den; s = im[r] / den;
+            } else {
+                m = sqrtf(fmaxf(re[r] * re[r] + im[r] * im[r], 1e-10f));
+                c = re[r] / m; s = im[r] / m;
+            }
+            if (real) real[row] = re[r];
+            if (imag) imag[row] = im[r];
+            if (mag) mag[row] = m;
+            if (cosv) cosv[row] = c;
+            if (sinv) sinv[row] = s;
+            if (x0 && f < FC) x0[((size_t)b * Tpad + ta + r) * FC + f] = m * s0[f] + h0[f];
+        }
+    }
+    if (x0 && !have_b && ta + 1 < Tpad)
+        for (int f = tid; f < FC; f += 256) x0[((size_t)b * Tpad + ta + 1) * FC + f] = 0.f;
+}
+
+// Inverse STFT, fused: a workgroup owns SPAN consecutive samples of the (n_fft/2-padded) output, runs the inverse
+// transforms of every frame whose window reaches into that span (two frames per complex transform) and overlap-adds
+// them in LDS in ascending frame order, then divides by the window-sum-square envelope of the same frames (clamped at
+// 1e-11) and writes the trimmed samples [n_fft/2, n_fft/2 + L).  No frame scratch in HBM.
+constexpr int ISTFT_SPAN = 16 * LASS_HOP;
+
+template <int N>
+__global__ __launch_bounds__(256) void istft2_kernel(const float* __restrict__ real, const float* __restrict__ imag,
+                                                     int T, int L, int hop, int wlen,
+                                                     const float2* __restrict__ tw2k, float* __restrict__ wav) {
+    __shared__ float2 A[N], Bf[N], TW[2048];
+    __shared__ float acc[ISTFT_SPAN], env[ISTFT_SPAN];
+    constexpr int NB = N / 2 + 1;
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int m0 = blockIdx.x * ISTFT_SPAN;  // first padded position of this span
+    const int woff = (N - wlen) / 2, wstride = 2048 / wlen;
+    for (int i = tid; i < 2048; i += 256) TW[i] = tw2k[i];
+    for (int i = tid; i < ISTFT_SPAN; i += 256) { acc[i] = 0.f; env[i] = 0.f; }
+    // frames whose window support [t*hop + woff, t*hop + woff + wlen) meets [m0, m0 + SPAN)
+    int t_lo = m0 - woff - wlen + 1;
+    t_lo = t_lo <= 0 ? 0 : (t_lo + hop - 1) / hop;
+    int t_hi = (m0 + ISTFT_SPAN - 1 - woff) / hop;
+    if (m0 + ISTFT_SPAN - 1 - woff < 0) t_hi = -1;
+    if (t_hi > T - 1) t_hi = T - 1;
+    __syncthreads();
+    for (int ta = t_lo; ta <= t_hi; ta += 2) {
+        const bool have_b = ta + 1 <= t_hi;
+        const size_t rowa = ((size_t)b * T + ta) * NB, rowb = rowa + NB;
+        // Z = Xa + i Xb with both spectra Hermitian-extended: bin k > N/2 is the conjugate of bin N-k
+        for (int k = tid; k < N; k += 256) {
+            const int kk = k <= N / 2 ? k : N - k;
+            const float sg = k <= N / 2 ? 1.f : -1.f;
+            const float ar = real[rowa + kk], ai = sg * imag[rowa + kk];
+            const float br = have_b ? real[rowb + kk] : 0.f, bi = have_b ? sg * imag[rowb + kk] : 0.f;
+            A[k] = make_float2(ar - bi, ai + br);
+        }
+        __syncthreads();
+        const float2* X = fft_c<N, true>(A, Bf, TW, tid);  // (xa, xb) * N
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            if (r == 1 && !have_b) break;
+            const int base = (ta + r) * hop + woff - m0;  // span position of window sample 0
+            for (int j = tid; j < wlen; j += 256) {
+                const int pos = base + j;
+                if (pos >= 0 && pos < ISTFT_SPAN) {
+                    const float wn = 0.5f - 0.5f * TW[j * wstride].x;
+                    const float2 x = X[woff + j];
+                    acc[pos] += (r == 0 ? x.x : x.y) * (wn * (1.0f / N));
+                    env[pos] += wn * wn;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < ISTFT_SPAN; i += 256) {
+        const int n = m0 + i - N / 2;
+        if (n >= 0 && n < L) wav[(size_t)b * L + n] = acc[i] / fmaxf(env[i], 1e-11f);
+    }
 }
 
 }  // namespace
-
-hipError_t lass_launch_stft(const float* wav, int B, int L, int T, int Tpad, const float2* tw, const float* win,
-                            float* mag, float* cosv, float* sinv, float* real, float* imag, float* x0,
-                            const float* s0, const float* h0, hipStream_t stream) {
-    if (B <= 0 || L <= LASS_NFFT / 2 || T != 1 + L / LASS_HOP || Tpad < T || (x0 && (!s0 || !h0)))
-        return hipErrorInvalidValue;
-    dim3 grid(x0 ? Tpad : T, B);
-    hipLaunchKernelGGL(stft_kernel, grid, dim3(256), 0, stream, wav, L, T, Tpad, tw, win, mag, cosv, sinv, real, imag,
-                       x0, s0, h0);
-    return hipGetLastError();
-}
-
-hipError_t lass_launch_istft_frames(const float* real, const float* imag, int B, int T, const float2* tw,
-                                    const float* win, float* frames, hipStream_t stream) {
-    if (B <= 0 || T <= 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(istft_frames_kernel, dim3(T, B), dim3(256), 0, stream, real, imag, T, tw, win, frames);
-    return hipGetLastError();
-}
-
-hipError_t lass_launch_istft_ola(const float* frames, int B, int T, int L, const float* win, float* wav,
-                                 hipStream_t stream) {
-    if (B <= 0 || T <= 0 || L <= 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(istft_ola_kernel, dim3((L + 255) / 256, B), dim3(256), 0, stream, frames, T, L, win, wav);
-    return hipGetLastError();
-}
 
 hipError_t lass_launch_multi_stft(const float* wav, int B, int L, int hop, int nwin, const int* n_fft,
                                   const float2* tw2k, float* const* mag, float* const* cosv, float* const* sinv,
@@ -280,5 +330,43 @@ hipError_t lass_launch_multi_stft(const float* wav, int B, int L, int hop, int n
     }
     const int T = 1 + L / hop;
     hipLaunchKernelGGL(multi_stft_kernel, dim3(T, B, nwin), dim3(256), 0, stream, wav, L, T, hop, tw2k, a);
+    return hipGetLastError();
+}
+
+hipError_t lass_launch_stft2(const float* wav, int B, int L, int n_fft, int hop, int T, int Tpad, int nbr,
+                             const StftBranch* br, int magphase_sem, const float* s0, const float* h0,
+                             const float2* tw2k, hipStream_t stream) {
+    if (B <= 0 || hop <= 0 || nbr <= 0 || nbr > LASS_MAX_STFT_WINDOWS || (n_fft != 1024 && n_fft != 2048) ||
+        L <= n_fft / 2 || T != 1 + L / hop || Tpad < T)
+        return hipErrorInvalidValue;
+    Stft2Args a;
+    a.nbr = nbr;
+    bool any_x0 = false;
+    for (int i = 0; i < nbr; ++i) {
+        const int wl = br[i].wlen;
+        if (wl <= 0 || wl > n_fft || (2048 % wl) != 0 || ((n_fft - wl) & 1)) return hipErrorInvalidValue;
+        if (br[i].x0 && (!s0 || !h0)) return hipErrorInvalidValue;
+        any_x0 |= br[i].x0 != nullptr;
+        a.wlen[i] = wl; a.mag[i] = br[i].mag; a.cosv[i] = br[i].cosv; a.sinv[i] = br[i].sinv;
+        a.real[i] = br[i].real; a.imag[i] = br[i].imag; a.x0[i] = br[i].x0;
+    }
+    dim3 grid(((any_x0 ? Tpad : T) + 1) / 2, B, nbr);
+#define LASS_STFT2(NN, MP) hipLaunchKernelGGL((stft2_kernel<NN, MP>), grid, dim3(256), 0, stream, wav, L, hop, T, Tpad, tw2k, a, s0, h0)
+    if (n_fft == 1024) { if (magphase_sem) LASS_STFT2(1024, true); else LASS_STFT2(1024, false); }
+    else               { if (magphase_sem) LASS_STFT2(2048, true); else LASS_STFT2(2048, false); }
+#undef LASS_STFT2
+    return hipGetLastError();
+}
+
+hipError_t lass_launch_istft2(const float* real, const float* imag, int B, int T, int L, int n_fft, int wlen, int hop,
+                              const float2* tw2k, float* wav, hipStream_t stream) {
+    if (B <= 0 || T <= 0 || L <= 0 || hop != LASS_HOP || (n_fft != 1024 && n_fft != 2048) || wlen <= 0 || wlen > n_fft ||
+        (2048 % wlen) != 0 || ((n_fft - wlen) & 1))
+        return hipErrorInvalidValue;
+    dim3 grid((n_fft / 2 + L + ISTFT_SPAN - 1) / ISTFT_SPAN, B);
+    if (n_fft == 1024)
+        hipLaunchKernelGGL(istft2_kernel<1024>, grid, dim3(256), 0, stream, real, imag, T, L, hop, wlen, tw2k, wav);
+    else
+        hipLaunchKernelGGL(istft2_kernel<2048>, grid, dim3(256), 0, stream, real, imag, T, L, hop, wlen, tw2k, wav);
     return hipGetLastError();
 }

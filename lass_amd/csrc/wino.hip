@@ -275,7 +275,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
             rowok |= (gy >= 0 && gy < p.H ? 1u : 0u) << i;
         }
         const __amdgpu_buffer_rsrc_t in_rsrc =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_b), 0, (PRE ? 1 : p.Cin) * HW * 4, 0x00020000);
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_b), 0, (int)((unsigned)(PRE ? 1 : p.Cin) * (unsigned)HW * 4u), 0x00020000);
         f2u ps[PRE ? 1 : 2][NIT][8];
         auto pload = [&](int ch, auto buf) {
             constexpr int BUF = decltype(buf)::value;
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
         const int nch = p.Cin / KC;  // even (host-checked)
         if (PRE) ra.load_x0(in_b, HW);
         const __amdgpu_buffer_rsrc_t in_rsrc =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_b), 0, (PRE ? 1 : p.Cin) * HW * 4, 0x00020000);
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_b), 0, (int)((unsigned)(PRE ? 1 : p.Cin) * (unsigned)HW * 4u), 0x00020000);
         ra.template load<0>(in_rsrc, 0u, HW);
         ra.template load<1>(in_rsrc, (unsigned)(KC * HW) * 4u, HW);
         const unsigned ulane = UA::lane_base(p.Nw, lane);
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
         const int oy = y0 + 2 * wty, ox = x0 + 2 * wtx;
         const bool okB = oy + 1 < p.H;
         const __amdgpu_buffer_rsrc_t in2_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(p.in2 + (size_t)b * p.in2_bs), 0, p.Cin2 * HW * 4, 0x00020000);
+            const_cast<float*>(p.in2 + (size_t)b * p.in2_bs), 0, (int)((unsigned)p.Cin2 * (unsigned)HW * 4u), 0x00020000);
         const unsigned voff1 = (unsigned)(cb * HW + min(oy, p.H - 2) * p.W + ox) * 4u, voff2 = voff1 + (unsigned)p.W * 4u;
         float2 rb[2 * NITB];
         auto loadB = [&](int ch) {
@@ -563,15 +563,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
             if (oy + 1 < p.H) *reinterpret_cast<float2*>(dst + p.W) = make_float2(y[1][0], y[1][1]);
             if (p.pool_out) {
                 const int Wo = p.W / 2;
+                const size_t pool_bs = p.pool_bs ? (size_t)p.pool_bs : (size_t)p.N * (p.H / p.pool_h) * Wo;
                 if (p.pool_h == 2) {
                     float sum = y[0][0] + y[0][1];  // reference summation order (row-major)
                     sum += y[1][0];
                     sum += y[1][1];
                     if (oy + 1 < p.H)
-                        p.pool_out[((size_t)b * p.N + n) * (p.H / 2) * Wo + (size_t)(oy >> 1) * Wo + (ox >> 1)] =
+                        p.pool_out[(size_t)b * pool_bs + (size_t)n * (p.H / 2) * Wo + (size_t)(oy >> 1) * Wo + (ox >> 1)] =
                             sum * 0.25f;
                 } else {
-                    float* pd = p.pool_out + ((size_t)b * p.N + n) * p.H * Wo + (size_t)oy * Wo + (ox >> 1);
+                    float* pd = p.pool_out + (size_t)b * pool_bs + (size_t)n * p.H * Wo + (size_t)oy * Wo + (ox >> 1);
                     if (oy < p.H) pd[0] = (y[0][0] + y[0][1]) * 0.5f;
                     if (oy + 1 < p.H) pd[Wo] = (y[1][0] + y[1][1]) * 0.5f;
                 }
@@ -727,7 +728,7 @@ hipError_t lass_launch_wino(ConvKind kind, const ConvArgs& p, hipStream_t stream
         case CONV2_SHORTCUT:
             if (!p.in2 || !p.w2_wino || !p.bias || p.Cin2 % KCB != 0) return hipErrorInvalidValue;
             if (p.mask_re) {  // fused output head: decoder_block6 geometry only
-                if (p.N != 32 || p.W != LASS_FCROP || !p.mask_w || !p.mask_b || !p.mask_mag || !p.mask_cos || !p.mask_sin ||
+                if (p.N != 32 || p.W + 1 != p.mask_nbins || !p.mask_w || !p.mask_b || !p.mask_mag || !p.mask_cos || !p.mask_sin ||
                     !p.mask_im || p.mask_T <= 0 || p.mask_T > p.H)
                     return hipErrorInvalidValue;
                 return launch_wino<F_PHASEB | F_BIAS | F_MASK>(p, stream);

@@ -22,7 +22,9 @@ def _stream(device) -> c_void_p:
 class Engine:
     """One context per (process, device)."""
 
-    def __init__(self, device="cuda:0"):
+    def __init__(self, device="cuda:0", multistft=None):
+        """multistft: None = ResUNet30 (models/resunet.py); (n_fft, win_lengths, mask_window) = the multi-resolution-STFT
+        separator (lass_create_multistft)."""
         self.lib = _lib.load()
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -32,10 +34,18 @@ class Engine:
         idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self.device = torch.device("cuda", idx)
         h = c_void_p()
-        rc = self.lib.lass_create(byref(h), idx)
+        self.multistft = None
+        if multistft is None:
+            rc = self.lib.lass_create(byref(h), idx)
+        else:
+            n_fft, wins, mask_window = int(multistft[0]), [int(w) for w in multistft[1]], int(multistft[2])
+            rc = self.lib.lass_create_multistft(byref(h), idx, n_fft, len(wins), (c_int * len(wins))(*wins), mask_window)
+            self.multistft = (n_fft, tuple(wins), mask_window)
         if rc < 0:
             raise _lib.LassError(f"lass_create failed ({rc}): {self.lib.lass_last_error(None).decode()}")
         self.ctx = h
+        self.n_fft = 1024 if multistft is None else self.multistft[0]
+        self.n_branches = 1 if multistft is None else len(self.multistft[1])
         self._ws: Dict[tuple, torch.Tensor] = {}
         self.finalized = False
 
@@ -149,9 +159,7 @@ class Engine:
         B, T, F = real.shape
         assert F == arch.N_BINS and imag.shape == real.shape
         wav = torch.empty(B, length, dtype=torch.float32, device=self.device)
-        frames = torch.empty(B, T, arch.N_FFT, dtype=torch.float32, device=self.device)
-        rc = self.lib.lass_istft(self.ctx, _ptr(real), _ptr(imag), B, T, length, _ptr(wav), _ptr(frames),
-                                 _stream(self.device))
+        rc = self.lib.lass_istft(self.ctx, _ptr(real), _ptr(imag), B, T, length, _ptr(wav), None, _stream(self.device))
         _lib.check(self.ctx, rc, "lass_istft")
         return wav
 
@@ -193,17 +201,66 @@ class Engine:
         return y, pool
 
     def front_end(self, wav: torch.Tensor):
-        """(B,L) -> (mag, cos, sin (B,T,513), x0 (B,Tpad,512)): STFT + bn0 + T-pad + F-crop (resunet.py:533-552)."""
+        """(B,L) -> (mag, cos, sin (B,T,n_fft/2+1), x0): STFT + bn0 + T-pad + F-crop (resunet.py:533-552).
+        x0 is (B,Tpad,512) for ResUNet30 and (n_windows,B,Tpad,1024) for the multi-STFT model (mag/cos/sin are then the
+        mask window's)."""
         wav = self._dev(wav)
         B, L = wav.shape
         T = arch.frames_for(L)
-        mk = lambda: torch.empty(B, T, arch.N_BINS, dtype=torch.float32, device=self.device)  # noqa: E731
+        nb = self.n_fft // 2 + 1
+        mk = lambda: torch.empty(B, T, nb, dtype=torch.float32, device=self.device)  # noqa: E731
         mag, cos, sin = mk(), mk(), mk()
-        x0 = torch.empty(B, arch.padded_frames(T), arch.F_CROP, dtype=torch.float32, device=self.device)
+        shape = (B, arch.padded_frames(T), nb - 1)
+        x0 = torch.empty((self.n_branches,) + shape if self.multistft else shape, dtype=torch.float32, device=self.device)
         rc = self.lib.lass_front_end(self.ctx, _ptr(wav), B, L, _ptr(mag), _ptr(cos), _ptr(sin), _ptr(x0),
                                      _stream(self.device))
         _lib.check(self.ctx, rc, "lass_front_end")
         return mag, cos, sin, x0
+
+    def stft_components(self, wav: torch.Tensor, n_fft: int, win_lengths, hop: int = arch.HOP):
+        """(B,L) -> {win: (mag, cos, sin)} each (B,1,T,n_fft//2+1): `calculate_stft_components` at a COMMON n_fft for
+        every win_length (zero-padded windows), one launch."""
+        wav = self._dev(wav)
+        B, L = wav.shape
+        T = 1 + L // hop
+        wins = [int(w) for w in win_lengths]
+        n = len(wins)
+        outs = {w: tuple(torch.empty(B, 1, T, n_fft // 2 + 1, dtype=torch.float32, device=self.device) for _ in range(3))
+                for w in wins}
+        arr = lambda i: (c_void_p * n)(*[outs[w][i].data_ptr() for w in wins])  # noqa: E731
+        rc = self.lib.lass_stft_components(self.ctx, _ptr(wav), B, L, n_fft, hop, n, (c_int * n)(*wins), arr(0), arr(1),
+                                           arr(2), _stream(self.device))
+        _lib.check(self.ctx, rc, "lass_stft_components")
+        return outs
+
+    def istft_nfft(self, real: torch.Tensor, imag: torch.Tensor, length: int, n_fft: int, win_length: int):
+        real, imag = self._dev(real), self._dev(imag)
+        B, T, F = real.shape
+        assert F == n_fft // 2 + 1 and imag.shape == real.shape
+        wav = torch.empty(B, length, dtype=torch.float32, device=self.device)
+        rc = self.lib.lass_istft_nfft(self.ctx, _ptr(real), _ptr(imag), B, T, length, n_fft, win_length, _ptr(wav),
+                                      _stream(self.device))
+        _lib.check(self.ctx, rc, "lass_istft_nfft")
+        return wav
+
+    def separate_components(self, mags, cos_mask: torch.Tensor, sin_mask: torch.Tensor, condition: torch.Tensor,
+                            length: int) -> torch.Tensor:
+        """Precomputed analysis in (the multi-STFT wrapper's input form): mags = [ (B,T,F) per analysis window in the
+        context's order ], cos / sin of the mask window -> waveform (B, length)."""
+        mags = [self._dev(m) for m in mags]
+        cos_mask, sin_mask, condition = self._dev(cos_mask), self._dev(sin_mask), self._dev(condition)
+        B, T, F = mags[0].shape
+        if len(mags) != self.n_branches or any(m.shape != (B, T, F) for m in mags) or F != self.n_fft // 2 + 1 \
+                or cos_mask.shape != (B, T, F) or sin_mask.shape != (B, T, F) or T != arch.frames_for(length) \
+                or condition.shape != (B, arch_cond()):
+            raise _lib.LassError("separate_components: inconsistent shapes")
+        out = torch.empty(B, length, dtype=torch.float32, device=self.device)
+        ws = self._workspace(B, length)
+        arr = (c_void_p * len(mags))(*[m.data_ptr() for m in mags])
+        rc = self.lib.lass_separate_components(self.ctx, arr, _ptr(cos_mask), _ptr(sin_mask), _ptr(condition), _ptr(out),
+                                               B, length, _ptr(ws), ws.numel(), _stream(self.device))
+        _lib.check(self.ctx, rc, "lass_separate_components")
+        return out
 
     def workspace_tensor(self, name: str, B: int, L: int) -> torch.Tensor:
         """View of a named intermediate that the last `separate` of shape (B, L) left in the workspace (f32 mode)."""

@@ -9,7 +9,10 @@ Host-side mirror of the reference's pre-compute path:
 
 All spectra are computed by liblass_hip (`lass_multi_stft`, lass_amd/csrc/stft.hip); there is no CPU fallback.
 The consumer of these files in the reference (`models/resunet_with_multistft.py`) is not runnable as shipped
-(SURVEY §2a), so only the producer side and the file format are reproduced.
+(SURVEY §2a): with n_fft = win_length its three branches have 129 / 257 / 1025 bins and cannot be concatenated.  The
+consumer built here (lass_amd/resunet_with_multistft.py, authored spec in DESIGN.md §9) reads the same wire format
+written with `n_fft=2048` for every window, which `calculate_stft_components(..., n_fft=2048, win_length=w, ...)` -
+a legal call of the reference's own function - produces.
 """
 from __future__ import annotations
 
@@ -25,9 +28,13 @@ from .engine import get_engine
 SUPPORTED_WINDOWS = (256, 512, 1024, 2048)
 
 
+COMMON_N_FFT = (1024, 2048)  # n_fft > win_length: every window zero-padded, centred, to one transform size
+
+
 def _check_cfg(n_fft, win_length, window, center, pad_mode):
-    if n_fft != win_length:
-        raise NotImplementedError("n_fft must equal win_length (scripts/precompute_stfts.py:577 sets n_fft = win_length)")
+    if n_fft != win_length and not (n_fft in COMMON_N_FFT and win_length < n_fft):
+        raise NotImplementedError("n_fft must equal win_length (scripts/precompute_stfts.py:577 sets n_fft = win_length) "
+                                  f"or be a common transform size {COMMON_N_FFT} larger than win_length")
     if win_length not in SUPPORTED_WINDOWS:
         raise NotImplementedError(f"win_length must be one of {SUPPORTED_WINDOWS}")
     if window != "hann" or not center or pad_mode != "reflect":
@@ -45,30 +52,36 @@ def _as_2d(waveform: torch.Tensor) -> torch.Tensor:
 
 
 def multi_resolution_stfts(waveform: torch.Tensor, win_lengths: Sequence[int], hop_length: int = 160,
-                           window: str = "hann", center: bool = True, pad_mode: str = "reflect"):
-    """{win_length: (magnitude, cos, sin)} each (B, 1, T, win_length//2+1), T = 1 + L // hop_length."""
+                           window: str = "hann", center: bool = True, pad_mode: str = "reflect",
+                           n_fft: Optional[int] = None):
+    """{win_length: (magnitude, cos, sin)}, T = 1 + L // hop_length.  n_fft=None: each window at n_fft = win_length
+    (scripts/precompute_stfts.py:577), shapes (B, 1, T, win_length//2+1).  n_fft=2048 (or 1024): every window at that
+    common transform size - the input format of lass_amd.resunet_with_multistft.ResUNet30 - shapes (B, 1, T, n_fft//2+1)."""
     for w in win_lengths:
-        _check_cfg(w, w, window, center, pad_mode)
+        _check_cfg(w if n_fft is None else n_fft, w, window, center, pad_mode)
     x = _as_2d(waveform)
-    return get_engine(x.device).multi_stft(x, list(win_lengths), hop_length)
+    if n_fft is None:
+        return get_engine(x.device).multi_stft(x, list(win_lengths), hop_length)
+    return get_engine(x.device).stft_components(x, n_fft, list(win_lengths), hop_length)
 
 
 def calculate_stft_components(waveform, n_fft, hop_length, win_length, window, center, pad_mode):
     """scripts/precompute_stfts.py:19-58: (magnitude, cos_phase, sin_phase), each (B, 1, T, n_fft//2+1), contiguous."""
     _check_cfg(n_fft, win_length, window, center, pad_mode)
-    return multi_resolution_stfts(waveform, [win_length], hop_length, window, center, pad_mode)[win_length]
+    return multi_resolution_stfts(waveform, [win_length], hop_length, window, center, pad_mode,
+                                  None if n_fft == win_length else n_fft)[win_length]
 
 
 def make_precomputed_items(mixtures: torch.Tensor, segments: torch.Tensor, texts: Sequence[str],
                            mixture_component_texts: Sequence[Sequence[str]], win_lengths: Sequence[int],
                            hop_length: int = 160, window: str = "hann", center: bool = True,
-                           pad_mode: str = "reflect") -> List[Dict[str, Any]]:
+                           pad_mode: str = "reflect", n_fft: Optional[int] = None) -> List[Dict[str, Any]]:
     """Per-item dicts exactly as scripts/precompute_stfts.py:596-622 builds them (tensors stay on the device; slices
     `t[k:k+1]` keep the leading batch axis of size 1)."""
     if mixtures.shape != segments.shape:
         raise ValueError("mixtures and segments must have the same shape")
-    mix = multi_resolution_stfts(mixtures, win_lengths, hop_length, window, center, pad_mode)
-    seg = multi_resolution_stfts(segments, win_lengths, hop_length, window, center, pad_mode)
+    mix = multi_resolution_stfts(mixtures, win_lengths, hop_length, window, center, pad_mode, n_fft)
+    seg = multi_resolution_stfts(segments, win_lengths, hop_length, window, center, pad_mode, n_fft)
     common = {"hop_length": hop_length, "window": window, "center": center, "pad_mode": pad_mode}
     items = []
     for k in range(mixtures.shape[0]):

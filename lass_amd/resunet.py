@@ -49,7 +49,7 @@ class ResUNet30(nn.Module):
                                       "condition_size=512 (config/audiosep_base.yaml)")
         self.input_channels, self.output_channels, self.condition_size = input_channels, output_channels, condition_size
         self.film_meta = self._film_meta()
-        for name, shape, kind in arch.param_specs(input_channels, output_channels, condition_size):
+        for name, shape, kind in self._param_specs():
             parts = name.split(".")
             mod: nn.Module = self
             for p in parts[:-1]:
@@ -66,11 +66,20 @@ class ResUNet30(nn.Module):
         self.compute_dtype = "f32"  # "bf16" = BASELINE configs[2] (bf16-MFMA convolutions, reduced precision)
         self.eval()
 
-    @staticmethod
-    def _film_meta() -> Dict:
+    # ---- what a variant of the model overrides (lass_amd/resunet_with_multistft.py) ---------------------------------
+    def _param_specs(self):
+        return arch.param_specs(self.input_channels, self.output_channels, self.condition_size)
+
+    def _film_sites(self):
+        return arch.film_sites()
+
+    def _make_engine(self, dev) -> Engine:
+        return Engine(dev)
+
+    def _film_meta(self) -> Dict:
         """Nested {module: {'beta1': C, 'beta2': C}} as get_film_meta returns (resunet.py:598-618)."""
         meta: Dict = {}
-        for site, c, _used in arch.film_sites():
+        for site, c, _used in self._film_sites():
             d = meta
             parts = site.split("->")
             for p in parts[:-1]:
@@ -96,7 +105,7 @@ class ResUNet30(nn.Module):
         return (self.compute_dtype,) + tuple((t.data_ptr(), t._version) for t in self.state_dict(keep_vars=True).values())
 
     def _device(self) -> torch.device:
-        return self.base.pre_conv.weight.device
+        return self.base.after_conv.weight.device
 
     def _ensure_engine(self) -> Engine:
         dev = self._device()
@@ -104,7 +113,7 @@ class ResUNet30(nn.Module):
             raise LassError("lass_amd.ResUNet30 computes on an MI355X only: move the module with .to('cuda'). "
                             "There is no CPU fallback.")
         if self._engine is None or self._engine.device != dev:
-            self._engine = Engine(dev)
+            self._engine = self._make_engine(dev)
             self._uploaded_sig = None
         sig = self._signature()
         if sig != self._uploaded_sig:

@@ -30,11 +30,14 @@ def _xavier_bound(shape: Tuple[int, ...], kind: str) -> float:
 
 
 def make_state_dict(seed: int = SEED, input_channels: int = 1, output_channels: int = 1,
-                    condition_size: int = 512) -> Dict[str, np.ndarray]:
-    """Seeded numpy state_dict with the reference's keys (float32; num_batches_tracked int64)."""
+                    condition_size: int = 512, specs=None) -> Dict[str, np.ndarray]:
+    """Seeded numpy state_dict with the reference's keys (float32; num_batches_tracked int64).  `specs` defaults to
+    arch.param_specs(...) (ResUNet30); pass arch.ms_param_specs(...) for the multi-STFT model."""
     rng = np.random.Generator(np.random.PCG64(seed))
     sd: Dict[str, np.ndarray] = {}
-    for name, shape, kind in arch.param_specs(input_channels, output_channels, condition_size):
+    if specs is None:
+        specs = arch.param_specs(input_channels, output_channels, condition_size)
+    for name, shape, kind in specs:
         if kind in ("conv_w", "tconv_w", "linear_w"):
             b = _xavier_bound(shape, kind)
             v = rng.uniform(-b, b, size=shape)
@@ -53,6 +56,11 @@ def make_state_dict(seed: int = SEED, input_channels: int = 1, output_channels: 
     sd["base.after_conv.bias"] = (sd["base.after_conv.bias"]
                                   + np.asarray([1.5, 2.0, -0.2] * output_channels, dtype=np.float32))
     return sd
+
+
+def make_state_dict_ms(seed: int = SEED + 4, win_lengths=arch.MS_WIN_LENGTHS) -> Dict[str, np.ndarray]:
+    """Seeded weights of the multi-STFT separator (arch.ms_param_specs)."""
+    return make_state_dict(seed, specs=arch.ms_param_specs(win_lengths=win_lengths))
 
 
 def make_condition(batch: int, seed: int = SEED, condition_size: int = 512, distinct: bool = True) -> np.ndarray:

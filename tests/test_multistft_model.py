@@ -1,0 +1,224 @@
+"""Multi-resolution-STFT separator (BASELINE configs[4]; authored spec: lass_amd/arch.py).
+
+PARITY UNPINNED against the reference: models/resunet_with_multistft.py cannot run and was not imported.
+What these tests hold:
+  CPU  - the oracle's zero-padded-window STFT / iSTFT equal torch.stft / torch.istft(n_fft=2048, win_length=w); the
+         oracle model is built only from oracle/resunet.py blocks that ARE pinned to the reference (tests/golden);
+         names / shapes of the module tree follow resunet_with_multistft.py:40-118.
+  GPU  - the HIP path (lass_create_multistft) against that oracle: stage level (analysis, synthesis, taps) and end to
+         end, tiny shape and the full configs[4] clip (30 s @ 32 kHz, L = 960 000)."""
+import numpy as np
+import pytest
+import torch
+
+from lass_amd import arch, synthetic
+from oracle import resunet as orr
+from oracle import resunet_multistft as oms
+
+DEV = "cuda:0"
+WINS = arch.MS_WIN_LENGTHS
+
+
+# ---- CPU -----------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("w", WINS)
+def test_oracle_padded_window_stft_equals_torch(w):
+    L = 8077
+    x = torch.randn(2, L, dtype=torch.float64, generator=torch.Generator().manual_seed(w))
+    re, im = oms.stft(x, w)
+    ts = torch.stft(x, 2048, 160, w, torch.hann_window(w, periodic=True, dtype=torch.float64), center=True,
+                    pad_mode="reflect", normalized=False, onesided=True, return_complex=True).transpose(1, 2)
+    assert re.shape == (2, 1, 1 + L // 160, 1025)
+    assert float((ts.real - re[:, 0]).abs().max()) < 1e-10 and float((ts.imag - im[:, 0]).abs().max()) < 1e-10
+
+
+def test_oracle_istft_equals_torch_istft_and_roundtrip():
+    L = 9000
+    x = torch.randn(2, L, dtype=torch.float64, generator=torch.Generator().manual_seed(5))
+    re, im = oms.stft(x, 512)
+    y = oms.istft(re, im, L, 512)
+    assert float((y - x).abs().max()) < 1e-10
+    spec = torch.complex(re[:, 0], im[:, 0]).transpose(1, 2)
+    ref = torch.istft(spec, 2048, 160, 512, torch.hann_window(512, periodic=True, dtype=torch.float64), center=True,
+                      length=L)
+    assert float((y - ref).abs().max()) < 1e-10
+
+
+def test_module_tree_names_and_shapes():
+    """resunet_with_multistft.py:40-118: ModuleDict branches keyed by str(win), FUSED_CH = 96 into encoder_block2,
+    32 + 96 into decoder_block6's ConvBlockRes; FiLM names carry the ModuleDict key."""
+    specs = {n: s for n, s, _ in arch.ms_param_specs()}
+    for w in WINS:
+        assert specs[f"base.pre_convs.{w}.weight"] == (32, 1, 1, 1)
+        assert specs[f"base.encoder_block1s.{w}.conv_block1.conv1.weight"] == (32, 32, 3, 3)
+        assert specs[f"film.encoder_block1s->{w}->conv_block1->beta2.weight"] == (32, 512)
+    assert specs["base.bn0.weight"] == (1025,)
+    assert specs["base.encoder_block2.conv_block1.conv1.weight"] == (64, 96, 3, 3)
+    assert specs["base.encoder_block2.conv_block1.shortcut.weight"] == (64, 96, 1, 1)
+    assert specs["base.decoder_block6.conv1.weight"] == (64, 32, 2, 2)
+    assert specs["base.decoder_block6.conv_block2.conv1.weight"] == (32, 128, 3, 3)
+    assert specs["film.decoder_block6->conv_block2->beta1.weight"] == (128, 512)
+    assert specs["base.decoder_block5.conv_block2.conv1.weight"] == (64, 128, 3, 3)  # trunk unchanged
+    from lass_amd.resunet_with_multistft import ResUNet30
+    m = ResUNet30(1, 1, 512)
+    assert set(m.state_dict()) == set(specs)
+    assert m.film_meta["encoder_block1s"]["2048"]["conv_block1"] == {"beta1": 32, "beta2": 32}
+    assert m.film_meta["decoder_block6"]["conv_block2"]["beta1"] == 128
+    with pytest.raises(NotImplementedError):
+        ResUNet30(1, 1, 512, win_lengths=(256, 2048))  # no 512 window to re-synthesise from
+
+
+def test_oracle_forward_tiny_is_finite_and_branch_sensitive():
+    sd = orr.to_torch(synthetic.make_state_dict_ms())
+    _, mix = synthetic.make_mixtures(1, 8000)
+    cond = torch.from_numpy(synthetic.make_condition(1))
+    taps = {}
+    out = oms.forward(sd, {"mixture": torch.from_numpy(mix)[:, None], "condition": cond}, taps=taps)["waveform"]
+    assert out.shape == (1, 1, 8000) and torch.isfinite(out).all() and float(out.abs().max()) > 1e-4
+    assert taps["x1"].shape == (1, 96, 64, 1024) and taps["x1_pool"].shape == (1, 96, 32, 512)
+    # every analysis branch reaches the output
+    sd2 = dict(sd)
+    sd2["base.pre_convs.256.weight"] = sd["base.pre_convs.256.weight"] * 1.5
+    out2 = oms.forward(sd2, {"mixture": torch.from_numpy(mix)[:, None], "condition": cond})["waveform"]
+    assert float((out2 - out).abs().max()) > 1e-6
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="CPU-only behaviour")
+def test_multistft_mirror_fails_loudly_on_cpu():
+    from lass_amd._lib import LassError
+    from lass_amd.resunet_with_multistft import ResUNet30
+    m = ResUNet30()
+    with pytest.raises(LassError):
+        m({"mixture": torch.zeros(1, 1, 8000), "condition": torch.zeros(1, 512)})
+
+
+# ---- GPU -----------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def ms_sd():
+    return synthetic.make_state_dict_ms()
+
+
+@pytest.fixture(scope="module")
+def ms_model(ms_sd):
+    from lass_amd.resunet_with_multistft import ResUNet30
+    m = ResUNet30(1, 1, 512)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in ms_sd.items()})
+    return m.to(DEV).eval()
+
+
+def _rms(a):
+    return float(a.double().pow(2).mean().sqrt())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("L", [16000, 8077, 1025])
+def test_stft_components_common_nfft_vs_oracle(ms_model, L):
+    """lass_stft_components (n_fft 2048, windows 256 / 512 / 2048, one launch) against the oracle's zero-padded-window
+    STFT + magphase."""
+    g = torch.Generator().manual_seed(L)
+    x = (torch.rand(3, L, generator=g) * 2 - 1) * 0.5
+    out = ms_model.engine.stft_components(x.to(DEV), 2048, WINS)
+    for w in WINS:
+        mag, cos, sin = (t.cpu() for t in out[w])
+        m_ref, c_ref, s_ref = oms.stft_components(x.double(), w)
+        assert mag.shape == m_ref.shape == (3, 1, 1 + L // 160, 1025)
+        scale = float(m_ref.max())
+        assert float((mag.double() - m_ref).abs().max()) < 2e-6 * scale + 1e-6
+        assert float((mag.double() * cos.double() - m_ref * c_ref).abs().max()) < 4e-6 * scale + 1e-6
+        assert float((mag.double() * sin.double() - m_ref * s_ref).abs().max()) < 4e-6 * scale + 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w", [512, 2048, 256])
+def test_istft_nfft_vs_oracle_and_roundtrip(ms_model, w):
+    L = 24000
+    _, mix = synthetic.make_mixtures(2, L)
+    x = torch.from_numpy(mix)
+    re, im = oms.stft(x, w)
+    eng = ms_model.engine
+    y = eng.istft_nfft(re[:, 0].contiguous().to(DEV), im[:, 0].contiguous().to(DEV), L, 2048, w).cpu()
+    ref = oms.istft(re, im, L, w)
+    assert float((y - ref).abs().max()) < 2e-6
+    assert float((y - x).abs().max()) < 2e-6   # hop 160 <= w / 1.6: perfect reconstruction
+
+
+@pytest.mark.gpu
+def test_multistft_tiny_vs_oracle_both_input_forms_and_taps(ms_model, ms_sd):
+    sd = orr.to_torch(ms_sd)
+    B, L = 2, 16000
+    _, mix = synthetic.make_mixtures(B, L)
+    cond = synthetic.make_condition(B)
+    taps = {}
+    ref = oms.forward(sd, {"mixture": torch.from_numpy(mix)[:, None], "condition": torch.from_numpy(cond)}, taps=taps)["waveform"]
+    inp = {"mixture": torch.from_numpy(mix)[:, None].to(DEV), "condition": torch.from_numpy(cond).to(DEV)}
+    out = ms_model(inp)["waveform"]
+    assert out.shape == (B, 1, L)
+    err = _rms(out.cpu() - ref)
+    assert err <= 1e-5, err
+    # taps read in place from the workspace: per-branch network inputs, the channel-concatenated skip and pool
+    eng = ms_model.engine
+    T = arch.frames_for(L)
+    for w in WINS:
+        x0 = eng.workspace_tensor(f"x0.{w}", B, L)
+        assert float((x0.cpu() - taps[f"x0.{w}"]).abs().max()) < 2e-5 * max(1.0, float(taps[f"x0.{w}"].abs().max()))
+    for name, key in (("encoder_block1", "x1"), ("encoder_block1.pool", "x1_pool"), ("encoder_block2", "encoder_block2"),
+                      ("decoder_block5", "decoder_block5")):
+        t = eng.workspace_tensor(name, B, L).cpu()
+        assert t.shape == taps[key].shape, (name, t.shape, taps[key].shape)
+        assert _rms(t - taps[key]) < 5e-6 * max(1.0, _rms(taps[key])), name
+    o_re = eng.workspace_tensor("out_real", B, L)[:, :, :T].cpu()
+    assert float((o_re - taps["out_real"]).abs().max()) < 2e-5 * max(1.0, float(taps["out_real"].abs().max()))
+    assert torch.all(eng.workspace_tensor("out_real", B, L)[..., 1024] == 0)   # Nyquist bin exactly zero
+    # the reference wrapper's input form: precomputed {win: (B,1,T,1025)} dicts + target_waveform
+    from lass_amd import precompute_stfts as ps
+    comp = ps.multi_resolution_stfts(inp["mixture"], WINS, n_fft=2048)
+    d = {"stft_mixture_mag": {w: comp[w][0] for w in WINS}, "stft_mixture_cos": {w: comp[w][1] for w in WINS},
+         "stft_mixture_sin": {w: comp[w][2] for w in WINS}, "condition": inp["condition"]}
+    out2 = ms_model(d, target_waveform=inp["mixture"])["waveform"]
+    assert out2.shape == (B, L)
+    assert float((out2 - out[:, 0]).abs().max()) < 1e-6
+    # and from CPU-resident precomputed tensors made by the oracle (the wire format as a file would deliver it)
+    mag, cos, sin = oms.components(torch.from_numpy(mix)[:, None])
+    d3 = {"stft_mixture_mag": mag, "stft_mixture_cos": cos, "stft_mixture_sin": sin, "condition": torch.from_numpy(cond)}
+    out3 = ms_model(d3, target_waveform=torch.from_numpy(mix))["waveform"]
+    assert _rms(out3.cpu() - ref[:, 0]) <= 1e-5
+
+
+@pytest.mark.gpu
+def test_multistft_ragged_lengths_and_batch_invariance(ms_model, ms_sd):
+    sd = orr.to_torch(ms_sd)
+    for B, L in ((1, 8000 + 77), (3, 5000)):
+        _, mix = synthetic.make_mixtures(B, L)
+        cond = synthetic.make_condition(B)
+        ref = oms.forward(sd, {"mixture": torch.from_numpy(mix)[:, None], "condition": torch.from_numpy(cond)})["waveform"]
+        out = ms_model({"mixture": torch.from_numpy(mix)[:, None].to(DEV), "condition": torch.from_numpy(cond).to(DEV)})["waveform"]
+        assert _rms(out.cpu() - ref) <= 1e-5
+        one = ms_model({"mixture": torch.from_numpy(mix)[:1, None].to(DEV), "condition": torch.from_numpy(cond)[:1].to(DEV)})["waveform"]
+        assert torch.equal(one[0], out[0])
+
+
+@pytest.mark.gpu
+def test_multistft_config5_30s_32khz_vs_oracle(ms_model, ms_sd):
+    """BASELINE configs[4] clip: 30 s @ 32 kHz = 960 000 samples, T = 6001 -> 6016 frames x 1024 bins; decoder_block6's
+    concat is 3.15 GB per clip (beyond 2^31: exercises the unsigned 32-bit addressing of the Winograd kernels)."""
+    sd = orr.to_torch(ms_sd)
+    L = 960000
+    segs = [synthetic.make_mixtures(1, 160000, first=20 + i)[1][0] for i in range(6)]
+    mix = np.concatenate(segs)[None, :L].astype(np.float32)
+    cond = synthetic.make_condition(1)
+    out = ms_model({"mixture": torch.from_numpy(mix)[:, None].to(DEV), "condition": torch.from_numpy(cond).to(DEV)})["waveform"]
+    torch.cuda.synchronize()
+    torch.set_num_threads(16)
+    ref = oms.forward(sd, {"mixture": torch.from_numpy(mix)[:, None], "condition": torch.from_numpy(cond)})["waveform"]
+    err, sig = _rms(out.cpu() - ref), _rms(ref)
+    assert sig > 1e-3 and err <= 1e-5, (err, sig)
+
+
+@pytest.mark.gpu
+def test_multistft_limits_and_modes(ms_model):
+    from lass_amd._lib import LassError
+    eng = ms_model.engine
+    with pytest.raises(LassError):
+        eng.workspace_bytes(1, 8192 * 160)      # concat would reach 4 GiB per clip
+    assert eng.workspace_bytes(1, 8100 * 160) > 0
+    with pytest.raises(NotImplementedError):
+        ms_model.set_compute_dtype("bf16")

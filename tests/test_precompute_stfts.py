@@ -69,8 +69,10 @@ def test_front_end_refuses_cpu_and_unsupported_configs():
     x = torch.zeros(1, 1, 4000)
     with pytest.raises(LassError):
         ps.calculate_stft_components(x, 512, 160, 512, "hann", True, "reflect")
+    with pytest.raises(LassError):  # common n_fft > win_length is supported (multi-STFT model input) - on the GPU only
+        ps.calculate_stft_components(x, 2048, 160, 512, "hann", True, "reflect")
     with pytest.raises(NotImplementedError):
-        ps.calculate_stft_components(x, 1024, 160, 512, "hann", True, "reflect")
+        ps.calculate_stft_components(x, 512, 160, 1024, "hann", True, "reflect")
     with pytest.raises(NotImplementedError):
         ps.calculate_stft_components(x, 300, 160, 300, "hann", True, "reflect")
     with pytest.raises(NotImplementedError):
