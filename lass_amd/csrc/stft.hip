@@ -285,7 +285,9 @@ __global__ __launch_bounds__(256) void istft2_kernel(const float* __restrict__ r
         // Z = Xa + i Xb with both spectra Hermitian-extended: bin k > N/2 is the conjugate of bin N-k
         for (int k = tid; k < N; k += 256) {
             const int kk = k <= N / 2 ? k : N - k;
-            const float sg = k <= N / 2 ? 1.f : -1.f;
+            // bins 0 and N/2 of a real frame's spectrum are real: their imaginary parts are ignored (sin(0) = sin(pi n)
+            // = 0 in the reference's inverse-DFT matrix) - and must not leak into the partner frame of the packed pair
+            const float sg = (kk == 0 || kk == N / 2) ? 0.f : (k <= N / 2 ? 1.f : -1.f);
             const float ar = real[rowa + kk], ai = sg * imag[rowa + kk];
             const float br = have_b ? real[rowb + kk] : 0.f, bi = have_b ? sg * imag[rowb + kk] : 0.f;
             A[k] = make_float2(ar - bi, ai + br);
