@@ -130,31 +130,22 @@ struct RawStage {
     }
 };
 
-// Weight-slab staging by LDS-DMA (global_load_lds, 16 B per lane, no VGPRs): NXI x KC rows of NT floats from
-// Uw[xi][Cin][Nw] into lu[row][NT] (row = xi_slot*KC + c).  One wave-instruction writes 1 KiB = RPI whole rows, lane-linear;
-// the bank swizzle (16-float halves of odd rows swapped, so the two k-rows a 32-lane group reads hit disjoint banks)
-// is therefore applied on the SOURCE address and undone by the fragment reader.
-template <int NXI, int NT, int KCH = KC>
+// Weight-slab staging by LDS-DMA (buffer_load ... lds, 16 B per lane, no VGPRs).  The transform-domain weights are stored
+// in global memory as the exact LDS image of a (chunk, 32-cout group) slab (wino_weights_kernel): 16 rows-of-xi x 4 kq x
+// 16 couts x {(k0,t0),(k0,t1),(k1,t0),(k1,t1)} = 16 KiB, so that a lane's A fragment for a whole xi step is one aligned
+// 16-byte word and the DMA is a plain linear copy: piece i of the workgroup's slab (WCO adjacent groups) goes from
+// slab + 1 KiB * i to lu + 1 KiB * i.
+template <int WCO>
 struct UDma {
-    static constexpr int RPI = 256 / NT;                 // rows per wave-instruction (4 or 8: never straddles a xi slot)
-    static constexpr int NINSTR = NXI * KCH / RPI / 4;   // wave-instructions per wave
-    static_assert(NXI * KCH % (RPI * 4) == 0 && KCH % RPI == 0, "rows split evenly; an instruction stays in one xi slot");
-    // Per-lane part of the source address (constant over chunks and instructions): row-in-instruction * Nw + swizzled col
-    // returned as a 32-bit BYTE offset from Uw + n0, so that an instruction's address is (uniform pointer) + (lane offset)
-    __device__ __forceinline__ static unsigned lane_base(int Nw, int lane) {
-        const int rl = lane / (NT / 4);                  // row within the instruction's RPI rows
-        const int colpos = (lane % (NT / 4)) * 4;
-        return 4u * (unsigned)(rl * Nw + (colpos ^ ((rl & 1) << 4)));  // r0 is even, so (r & 1) == (rl & 1)
-    }
-    // lds_base: LDS byte address of lu (uniform).  c0: first channel of the chunk.
-    __device__ __forceinline__ static void issue(v4i32 rsrc, unsigned lane_off, int Cin, int Nw, int c0,
-                                                 unsigned lds_base, int wave) {
+    static constexpr int NINSTR = 4 * WCO;  // wave-instructions per wave (16 * WCO pieces over 4 waves)
+    static constexpr int SLAB_BYTES = 16384 * WCO;
+    // slab_byte0: byte offset of this chunk's slab in the weight buffer (wave-uniform)
+    __device__ __forceinline__ static void issue(v4i32 rsrc, unsigned lane_off, unsigned slab_byte0, unsigned lds_base,
+                                                 int wave) {
 #pragma unroll
         for (int i = 0; i < NINSTR; ++i) {
-            const int r0 = (wave * NINSTR + i) * RPI;    // wave-uniform
-            const int xi = r0 / KCH, c = r0 % KCH;
-            const unsigned soff = (unsigned)((xi * Cin + c0 + c) * Nw) * 4u;  // uniform
-            lds_dma_16B(rsrc, lane_off, soff, lds_base + (unsigned)(r0 * NT * 4));  // M0 = LDS byte address of this 1-KiB piece
+            const unsigned piece = (unsigned)(wave * NINSTR + i) * 1024u;  // wave-uniform
+            lds_dma_16B(rsrc, lane_off, slab_byte0 + piece, lds_base + piece);
         }
     }
 };
@@ -179,12 +170,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
     constexpr int NWT = 16 * WWT;
     constexpr int OR_ = 2 * (NWT / PWT), OC = 2 * PWT;  // output rows / cols of the block
     constexpr int IR = OR_ + 2, IP = OC + 2;
-    constexpr int VP = NWT + 16;  // V row pitch (floats): spreads the 4 k-rows of a fragment read over the banks
+    // V image: 64 rows (xi, kq) of NWT tiles x {k-step 0, k-step 1}; the row pitch is = 128 B mod 256 B so that the two
+    // kq rows a 32-lane group reads with one ds_read_b64 fall into different halves of the 64 banks
+    constexpr int VP = 2 * NWT + 32;
     using RA = RawStage<IR, IP, 1, KC, PRO, PRE>;
-    using UA = UDma<16, NT>;
-    using UB = UDma<4, NT, KCB>;
+    using UA = UDma<WCO>;
     constexpr int RAW_F = PATCH ? 0 : KC * IR * IP;
-    constexpr int V_F = 16 * KC * VP;
+    constexpr int V_F = 64 * VP;
     constexpr int U_F = 16 * KC * NT;
     constexpr int MAXC = 768;  // largest Cin of a 3x3 conv in the network (decoder_block1/2.conv1)
     constexpr bool MASK = (FLAGS & F_MASK) != 0;
@@ -247,10 +239,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
             for (int r = 0; r < 4; ++r) acc[xi][t][r] = 0.f;
 
     const int kq = lane >> 4, l15 = lane & 15;
-    const float* bfrag = lv + kq * VP + wwt * 16 + l15;
-    const int sw = (kq & 1) * 16;  // undo the LDS-DMA source swizzle: odd rows hold their 16-float halves swapped
-    const float* afrag0 = lu + kq * NT + wco * 32 + sw + l15;         // cout tile 0
-    const float* afrag1 = lu + kq * NT + wco * 32 + (16 - sw) + l15;  // cout tile 1
+    const float* bfrag = lv + kq * VP + (wwt * 16 + l15) * 2;   // row (xi, kq), this lane's tile: {k-step 0, k-step 1}
+    const float* afrag = lu + wco * 4096 + kq * 64 + l15 * 4;   // group wco, row (xi, kq), this lane's cout: 4 floats
+    const unsigned slab_pitch = (unsigned)(p.Nw / 32) * 16384u;  // bytes between the slabs of consecutive chunks
+    const unsigned slab_n0 = (unsigned)(n0 / 32) * 16384u;
 
     // ---- main phase: 3x3 over p.in ------------------------------------------------------------------------------
     // Per chunk:  barrier | raw(ch) regs->LDS | issue U(ch) LDS-DMA | issue raw(ch+2) loads | barrier |
@@ -320,28 +312,29 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
                     tt[2][jx] = d[2][jx] - d[1][jx];
                     tt[3][jx] = d[1][jx] - d[3][jx];
                 }
-                float* dst = lv + (cb + it * CSTEP) * VP + wt;
+                const int cl = cb + it * CSTEP;  // channel within the chunk: k-step cl / 4, row kq = cl % 4
+                float* dst = lv + (cl & 3) * VP + wt * 2 + (cl >> 2);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    dst[(4 * i + 0) * (KC * VP)] = tt[i][0] - tt[i][2];
-                    dst[(4 * i + 1) * (KC * VP)] = tt[i][1] + tt[i][2];
-                    dst[(4 * i + 2) * (KC * VP)] = tt[i][2] - tt[i][1];
-                    dst[(4 * i + 3) * (KC * VP)] = tt[i][1] - tt[i][3];
+                    dst[(4 * i + 0) * (4 * VP)] = tt[i][0] - tt[i][2];
+                    dst[(4 * i + 1) * (4 * VP)] = tt[i][1] + tt[i][2];
+                    dst[(4 * i + 2) * (4 * VP)] = tt[i][2] - tt[i][1];
+                    dst[(4 * i + 3) * (4 * VP)] = tt[i][1] - tt[i][3];
                 }
             }
         };
         const int nch = p.Cin / KC;  // even (host-checked)
         pload(0, std::integral_constant<int, 0>{});
         if (!PRE) pload(1, std::integral_constant<int, 1>{});
-        const unsigned ulane = UA::lane_base(p.Nw, lane);
-        const v4i32 uw_n0 = make_rsrc_words(p.w_wino + n0, (unsigned)(16 * p.Cin * p.Nw - n0) * 4u);
+        const unsigned ulane = (unsigned)lane * 16u;
+        const v4i32 uw_n0 = make_rsrc_words(p.w_wino, (unsigned)(16 * p.Cin * p.Nw) * 4u);
         lds_barrier();  // prologue tables visible
         auto chunk = [&](int ch, auto buf) {
             constexpr int BUF = decltype(buf)::value;
             lds_barrier();  // previous chunk's MFMAs have finished reading V / U
             pprocess(ch, buf);
             __builtin_amdgcn_sched_barrier(0);
-            UA::issue(uw_n0, ulane, p.Cin, p.Nw, ch * KC, lu_addr, wave);
+            UA::issue(uw_n0, ulane, (unsigned)ch * slab_pitch + slab_n0, lu_addr, wave);
             __builtin_amdgcn_sched_barrier(0);
             const bool pf = !PRE && ch + 2 < nch;
             if (pf) pload(ch + 2, buf);
@@ -351,7 +344,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
             else
                 wait_vmcnt<0>();
             lds_barrier();  // V visible, every wave's U rows landed
-            gemm_steps<16 * (KC / 4), NT, VP>(afrag0, afrag1, bfrag, acc, [](int s) { return s / (KC / 4); });
+            gemm_steps<16, 256, 4 * VP>(afrag, bfrag, acc, [](int s) { return s; });
         };
         for (int ch = 0; ch < nch; ch += 2) {
             chunk(ch, std::integral_constant<int, 0>{});
@@ -366,8 +359,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
             __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_b), 0, (int)((unsigned)(PRE ? 1 : p.Cin) * (unsigned)HW * 4u), 0x00020000);
         ra.template load<0>(in_rsrc, 0u, HW);
         ra.template load<1>(in_rsrc, (unsigned)(KC * HW) * 4u, HW);
-        const unsigned ulane = UA::lane_base(p.Nw, lane);
-        const v4i32 uw_n0 = make_rsrc_words(p.w_wino + n0, (unsigned)(16 * p.Cin * p.Nw - n0) * 4u);
+        const unsigned ulane = (unsigned)lane * 16u;
+        const v4i32 uw_n0 = make_rsrc_words(p.w_wino, (unsigned)(16 * p.Cin * p.Nw) * 4u);
         lds_barrier();  // prologue tables visible
         auto chunk = [&](int ch, auto buf) {
             constexpr int BUF = decltype(buf)::value;
@@ -380,7 +373,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
 #endif
             ra.template store<BUF>(lraw, lds_sc + ch * KC, lds_sh + ch * KC, tid, lds_pw + ch * KC, lds_pb + ch * KC);
             __builtin_amdgcn_sched_barrier(0);
-            UA::issue(uw_n0, ulane, p.Cin, p.Nw, ch * KC, lu_addr, wave);
+            UA::issue(uw_n0, ulane, (unsigned)ch * slab_pitch + slab_n0, lu_addr, wave);
             __builtin_amdgcn_sched_barrier(0);
             const bool pf = ch + 2 < nch;
             if (pf) ra.template load<BUF>(in_rsrc, (unsigned)((ch + 2) * KC * HW) * 4u, HW);
@@ -414,13 +407,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
                     tt[2][jx] = d[2][jx] - d[1][jx];
                     tt[3][jx] = d[1][jx] - d[3][jx];
                 }
-                float* dst = lv + c * VP + wt;
+                float* dst = lv + (c & 3) * VP + wt * 2 + (c >> 2);  // row kq = c % 4, k-step c / 4
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    dst[(4 * i + 0) * (KC * VP)] = tt[i][0] - tt[i][2];
-                    dst[(4 * i + 1) * (KC * VP)] = tt[i][1] + tt[i][2];
-                    dst[(4 * i + 2) * (KC * VP)] = tt[i][2] - tt[i][1];
-                    dst[(4 * i + 3) * (KC * VP)] = tt[i][1] - tt[i][3];
+                    dst[(4 * i + 0) * (4 * VP)] = tt[i][0] - tt[i][2];
+                    dst[(4 * i + 1) * (4 * VP)] = tt[i][1] + tt[i][2];
+                    dst[(4 * i + 2) * (4 * VP)] = tt[i][2] - tt[i][1];
+                    dst[(4 * i + 3) * (4 * VP)] = tt[i][1] - tt[i][3];
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -436,7 +429,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
             const long long t5 = clock64();
 #endif
             // 16 GEMMs: M_xi += U_xi (32 couts x 8 cin) * V_xi (8 cin x 16 tiles)
-            gemm_steps<16 * (KC / 4), NT, VP>(afrag0, afrag1, bfrag, acc, [](int s) { return s / (KC / 4); });
+            gemm_steps<16, 256, 4 * VP>(afrag, bfrag, acc, [](int s) { return s; });
 #ifdef LASS_CONV_DIAG
             dg[0] += t1 - t0; dg[1] += t2 - t1; dg[2] += t3 - t2; dg[3] += t4 - t3; dg[4] += t5 - t4;
             dg[5] += clock64() - t5;
@@ -472,8 +465,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
         };
         const int nch = p.Cin2 / KCB;
         loadB(0);
-        const unsigned ulane = UB::lane_base(p.Nw, lane);
-        const v4i32 uw_n0 = make_rsrc_words(p.w2_wino + n0, (unsigned)(4 * p.Cin2 * p.Nw - n0) * 4u);
+        const unsigned ulane = (unsigned)lane * 16u;
+        const v4i32 uw_n0 = make_rsrc_words(p.w2_wino, (unsigned)(4 * p.Cin2 * p.Nw) * 4u);
         for (int ch = 0; ch < nch; ++ch) {
             lds_barrier();  // previous chunk's MFMAs have finished reading V / U
 #pragma unroll
@@ -482,14 +475,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
                 if (!okB) { r1 = make_float2(0.f, 0.f); r2 = r1; }
                 const float t1a = r1.x + r2.x, t1b = r1.y + r2.y;  // tt[1][1], tt[1][2]
                 const float t2a = r2.x - r1.x, t2b = r2.y - r1.y;  // tt[2][1], tt[2][2]
-                float* dst = lv + (cb + it * CSTEP) * VP + wt;
-                dst[0 * (KCB * VP)] = t1a + t1b;  // V[1][1]
-                dst[1 * (KCB * VP)] = t1b - t1a;  // V[1][2]
-                dst[2 * (KCB * VP)] = t2a + t2b;  // V[2][1]
-                dst[3 * (KCB * VP)] = t2b - t2a;  // V[2][2]
+                // channel cl of the 32-chunk: 8-channel pair-step cl / 8, k-step (cl % 8) / 4, row kq = cl % 4; the image
+                // rows are (xi slot, pair-step, kq): one xi slot = 16 rows
+                const int cl = cb + it * CSTEP;
+                float* dst = lv + ((cl >> 3) * 4 + (cl & 3)) * VP + wt * 2 + ((cl >> 2) & 1);
+                dst[0 * (16 * VP)] = t1a + t1b;  // V[1][1]
+                dst[1 * (16 * VP)] = t1b - t1a;  // V[1][2]
+                dst[2 * (16 * VP)] = t2a + t2b;  // V[2][1]
+                dst[3 * (16 * VP)] = t2b - t2a;  // V[2][2]
             }
             __builtin_amdgcn_sched_barrier(0);
-            UB::issue(uw_n0, ulane, p.Cin2, p.Nw, ch * KCB, lu_addr, wave);
+            UA::issue(uw_n0, ulane, (unsigned)ch * slab_pitch + slab_n0, lu_addr, wave);
             __builtin_amdgcn_sched_barrier(0);
             const bool pf = ch + 1 < nch;
             if (pf) loadB(ch + 1);
@@ -499,8 +495,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
             else
                 wait_vmcnt<0>();
             lds_barrier();  // V visible, every wave's U rows landed
-            gemm_steps<4 * (KCB / 4), NT, VP>(afrag0, afrag1, bfrag, acc, [](int s) {
-                const int q = s / (KCB / 4);
+            gemm_steps<16, 256, 4 * VP>(afrag, bfrag, acc, [](int s) {
+                const int q = s / 4;                // 4 pair-steps (32 channels) per xi slot
                 return (q >> 1) * 4 + (q & 1) + 5;  // 5, 6, 9, 10
             });
         }
@@ -607,7 +603,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
 #endif
 }
 
-// U[xi][cin][cout] = (G g G^T)[xi] for g = w[cout][cin][3][3];  G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+// Transform-domain weights U_xi[cin][cout] = (G g G^T)[xi] for g = w[cout][cin][3][3], G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],
+// [0,0,1]], stored as the LDS images the kernel DMAs (see UDma): slab (chunk = cin / 8, group = cout / 32) of 4096 floats,
+// element [xi][kq = cin % 4][l15 = cout % 16][j = 2 * ((cin % 8) / 4) + (cout % 32) / 16].
 __global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restrict__ w, int Cout, int Cin,
                                                            float* __restrict__ U) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;  // (cin, cout), cout fastest
@@ -621,14 +619,17 @@ __global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restri
     double t[4][3];
     for (int a = 0; a < 4; ++a)
         for (int c = 0; c < 3; ++c) t[a][c] = G[a][0] * gg[0][c] + G[a][1] * gg[1][c] + G[a][2] * gg[2][c];
+    float* slab = U + ((size_t)(ci / 8) * (Cout / 32) + co / 32) * 4096;
+    const int e = (ci & 3) * 64 + (co & 15) * 4 + 2 * ((ci & 7) >> 2) + ((co & 31) >> 4);
     for (int a = 0; a < 4; ++a)
         for (int c = 0; c < 4; ++c) {
             const double u = t[a][0] * G[c][0] + t[a][1] * G[c][1] + t[a][2] * G[c][2];
-            U[((size_t)(a * 4 + c) * Cin + ci) * Cout + co] = (float)u;
+            slab[(a * 4 + c) * 256 + e] = (float)u;
         }
 }
 
-// Shortcut (1x1) weights in the transform domain: q = (i-1)*2 + (j-1), i,j in {1,2}: G[i][1]*w*G[j][1] = +-w/4
+// Shortcut (1x1) weights in the transform domain: q = (i-1)*2 + (j-1), i,j in {1,2}: G[i][1]*w*G[j][1] = +-w/4.
+// Slab (chunk = cin / 32, group = cout / 32) of 4096 floats, element [q][pair-step = (cin % 32) / 8][kq][l15][j].
 __global__ __launch_bounds__(256) void wino_shortcut_weights_kernel(const float* __restrict__ w, int Cout, int Cin,
                                                                     float* __restrict__ U) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -636,7 +637,9 @@ __global__ __launch_bounds__(256) void wino_shortcut_weights_kernel(const float*
     const int co = (int)(i % Cout), ci = (int)(i / Cout);
     const float v = w[(size_t)co * Cin + ci] * 0.25f;
     const float sgn[4] = {1.f, -1.f, -1.f, 1.f};
-    for (int q = 0; q < 4; ++q) U[((size_t)q * Cin + ci) * Cout + co] = sgn[q] * v;
+    float* slab = U + ((size_t)(ci / 32) * (Cout / 32) + co / 32) * 4096;
+    const int e = (((ci & 31) >> 3) * 4 + (ci & 3)) * 64 + (co & 15) * 4 + 2 * ((ci & 7) >> 2) + ((co & 31) >> 4);
+    for (int q = 0; q < 4; ++q) slab[q * 1024 + e] = sgn[q] * v;
 }
 
 template <int FLAGS, bool PATCH>
@@ -713,7 +716,7 @@ hipError_t launch_wino(const ConvArgs& p, hipStream_t stream) {
 bool lass_wino_supported(const ConvArgs& p) {
     static const bool small_ok = [] { const char* e = getenv("LASS_WINO_SMALL"); return !e || atoi(e) != 0; }();
     const bool w_ok = (p.W >= 32 && (p.W % 32) == 0) || (small_ok && (p.W == 16 || p.W == 8) && p.N % 64 == 0);
-    return w_ok && (p.H % 2) == 0 && p.Cin % (2 * KC) == 0 && p.N % 32 == 0 && (p.Nw % 4) == 0;
+    return w_ok && (p.H % 2) == 0 && p.Cin % (2 * KC) == 0 && p.N % 32 == 0 && (p.Nw % 32) == 0;
 }
 
 hipError_t lass_launch_wino(ConvKind kind, const ConvArgs& p, hipStream_t stream) {

@@ -42,28 +42,36 @@ __device__ __forceinline__ void lds_dma_16B(v4i32 rsrc, unsigned lane_off, unsig
         : "memory");
 }
 
-// S k-steps of 2 MFMAs (v_mfma_f32_16x16x4_f32); LDS row of step s = s*4 (+ lane>>4).  The three fragment reads of
-// step s+PFD are issued before the MFMAs of step s (pinned: hipcc sinks them otherwise and then waits lgkmcnt(0) in
-// front of every MFMA pair).
-template <int S, int UPITCH, int VPITCH, typename XiOf>
-__device__ __forceinline__ void gemm_steps(const float* afrag0, const float* afrag1, const float* bfrag,
-                                           f32x4 (&acc)[16][2], XiOf xi_of) {
-    constexpr int PFD = 3;
-    float bv[PFD + 1], a0[PFD + 1], a1[PFD + 1];
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// One chunk = NS steps of 4 MFMAs (v_mfma_f32_16x16x4_f32): a step covers 2 k-steps (8 input channels) x 2 cout tiles of
+// one xi.  Per step a lane reads ONE 16-byte A fragment {(k0,t0), (k0,t1), (k1,t0), (k1,t1)} (ds_read_b128) and ONE
+// 8-byte B fragment {k0, k1} (ds_read_b64): 2 LDS instructions and 6 LDS-array cycles per 4 MFMAs, where scalar reads
+// took 6 instructions and 12 cycles (ds_read_b32 runs at half the LDS rate).  The reads of step s+PFD are issued before
+// the MFMAs of step s (pinned: hipcc sinks them otherwise and then waits lgkmcnt(0) in front of every MFMA).
+// The two accumulators of a step alternate, so no MFMA depends on its predecessor (40-cycle dependent latency).
+template <int NS, int AST, int BST, typename XiOf>
+__device__ __forceinline__ void gemm_steps(const float* afrag, const float* bfrag, f32x4 (&acc)[16][2], XiOf xi_of) {
+    constexpr int PFD = 2;
+    f32x4 av[PFD + 1];
+    f32x2 bv[PFD + 1];
     auto rd = [&](int s) {
-        bv[s % (PFD + 1)] = bfrag[(s * 4) * VPITCH];
-        a0[s % (PFD + 1)] = afrag0[(s * 4) * UPITCH];
-        a1[s % (PFD + 1)] = afrag1[(s * 4) * UPITCH];
+        av[s % (PFD + 1)] = *reinterpret_cast<const f32x4*>(afrag + s * AST);
+        bv[s % (PFD + 1)] = *reinterpret_cast<const f32x2*>(bfrag + s * BST);
     };
 #pragma unroll
-    for (int s = 0; s < PFD && s < S; ++s) rd(s);
+    for (int s = 0; s < PFD && s < NS; ++s) rd(s);
 #pragma unroll
-    for (int s = 0; s < S; ++s) {
-        if (s + PFD < S) rd(s + PFD);
+    for (int s = 0; s < NS; ++s) {
+        if (s + PFD < NS) rd(s + PFD);
         __builtin_amdgcn_sched_barrier(0);
         const int xi = xi_of(s);
-        acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s % (PFD + 1)], bv[s % (PFD + 1)], acc[xi][0], 0, 0, 0);
-        acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s % (PFD + 1)], bv[s % (PFD + 1)], acc[xi][1], 0, 0, 0);
+        const f32x4 a = av[s % (PFD + 1)];
+        const f32x2 b = bv[s % (PFD + 1)];
+        acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc[xi][0], 0, 0, 0);
+        acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.x, acc[xi][1], 0, 0, 0);
+        acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.y, acc[xi][0], 0, 0, 0);
+        acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.y, acc[xi][1], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
 }
