@@ -83,6 +83,7 @@ struct ConvArgs {
                                  // produces a channel slice of a wider pooled tensor passes the wide tensor's stride.
     int pool_h = 2;              // vertical pool factor (1 or 2); horizontal is 2
     long long* dbg = nullptr;  // diagnostic builds (-DLASS_CONV_DIAG) only: 8 int64 per block
+    int exp = 0;  // diagnostic builds only: timing-experiment switches (env LASS_EXP, see wino.hip)
 };
 
 enum ConvKind { CONV1_ACT = 0, CONV2_IDENT = 1, CONV2_SHORTCUT = 2, TCONV_ACT = 3, CONV1_ACT_PRE = 4, CONV2_IDENT_PRE = 5 };

@@ -35,20 +35,37 @@ constexpr int NTHREADS = 256;
 constexpr int KC = 8;
 constexpr int KCB = 32;  // shortcut phase: 32 channels x 4 xi per chunk (the same 128 LDS rows and 64 MFMAs as a 3x3 chunk)
 
+// Wave priority by phase.  A wave's staging / transform chain (a few dozen VALU and LDS instructions strung between
+// barriers) is longer than its MFMA phase, and its VALU instructions queue behind the SIMD partner's back-to-back f32
+// MFMAs (which occupy the vector issue port): the preparing wave is the critical path, so it gets the higher priority.
+#ifndef LASS_PRIO
+#define LASS_PRIO 1
+#endif
+__device__ __forceinline__ void prep_prio() {
+#if LASS_PRIO
+    __builtin_amdgcn_s_setprio(2);
+#endif
+}
+__device__ __forceinline__ void mfma_prio() {
+#if LASS_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+}
+
 // Halo-tile staging: [KC][IR][IP] raw (activated) input, walked in channel pairs (see conv.hip Phase).
-template <int IR, int IP, int HALO, int KCH, bool PRO, bool PRE = false>
+template <int IR, int IP, int HALO, int KCH, bool PRO, bool PRE = false, int NTH = NTHREADS>
 struct RawStage {
     static constexpr int CH_ELEMS = IR * IP;
     static constexpr int G = 2;
     static constexpr int NGRP = KCH / G;
     static constexpr int GRP_ELEMS = G * CH_ELEMS;
-    static constexpr int NPASS = (GRP_ELEMS + NTHREADS - 1) / NTHREADS;
+    static constexpr int NPASS = (GRP_ELEMS + NTH - 1) / NTH;
     unsigned goff[NPASS];  // BYTE offset of this thread's element from the chunk's first channel (uniform base + 32-bit lane offset -> saddr loads)
     unsigned okbits;
     float v[PRE ? 1 : 2][PRE ? 1 : NGRP][NPASS];  // two chunks in flight (PRE: x0 at this thread's positions, loaded once)
 
     __device__ __forceinline__ static int upos(int tid, int k) {
-        const int u = tid + k * NTHREADS;
+        const int u = tid + k * NTH;
         return u < GRP_ELEMS ? u : GRP_ELEMS - 1;
     }
     __device__ __forceinline__ void init(int tid, int y0, int x0, int H, int W) {
@@ -135,9 +152,9 @@ struct RawStage {
 // 16 couts x {(k0,t0),(k0,t1),(k1,t0),(k1,t1)} = 16 KiB, so that a lane's A fragment for a whole xi step is one aligned
 // 16-byte word and the DMA is a plain linear copy: piece i of the workgroup's slab (WCO adjacent groups) goes from
 // slab + 1 KiB * i to lu + 1 KiB * i.
-template <int WCO>
+template <int WCO, int NW = 4>
 struct UDma {
-    static constexpr int NINSTR = 4 * WCO;  // wave-instructions per wave (16 * WCO pieces over 4 waves)
+    static constexpr int NINSTR = 16 * WCO / NW;  // wave-instructions per wave (16 * WCO pieces over NW waves)
     static constexpr int SLAB_BYTES = 16384 * WCO;
     // slab_byte0: byte offset of this chunk's slab in the weight buffer (wave-uniform)
     __device__ __forceinline__ static void issue(v4i32 rsrc, unsigned lane_off, unsigned slab_byte0, unsigned lds_base,
@@ -226,6 +243,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
     }
     if (MASK && tid < 99) lds_mw[tid] = tid < 96 ? p.mask_w[tid] : p.mask_b[tid - 96];
 
+#ifdef LASS_CONV_DIAG
+    const int EXPF = p.exp;  // timing experiments (LASS_EXP; results are wrong when set): 1 no U DMA, 2 no transform,
+                             // 4 no raw staging, 8 no MFMA
+#else
+    constexpr int EXPF = 0;
+#endif
 #ifdef LASS_CONV_DIAG
     const long long k_c0 = clock64(), k_r0 = wall_clock64();
     long long dg[6] = {0, 0, 0, 0, 0, 0};
@@ -332,6 +355,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
         auto chunk = [&](int ch, auto buf) {
             constexpr int BUF = decltype(buf)::value;
             lds_barrier();  // previous chunk's MFMAs have finished reading V / U
+            prep_prio();
             pprocess(ch, buf);
             __builtin_amdgcn_sched_barrier(0);
             UA::issue(uw_n0, ulane, (unsigned)ch * slab_pitch + slab_n0, lu_addr, wave);
@@ -344,6 +368,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
             else
                 wait_vmcnt<0>();
             lds_barrier();  // V visible, every wave's U rows landed
+            mfma_prio();
             gemm_steps<16, 256, 4 * VP>(afrag, bfrag, acc, [](int s) { return s; });
         };
         for (int ch = 0; ch < nch; ch += 2) {
@@ -368,14 +393,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
             const long long t0 = clock64();
 #endif
             lds_barrier();  // previous chunk's MFMAs have finished reading V / U
+            prep_prio();
 #ifdef LASS_CONV_DIAG
             const long long t1 = clock64();
 #endif
-            ra.template store<BUF>(lraw, lds_sc + ch * KC, lds_sh + ch * KC, tid, lds_pw + ch * KC, lds_pb + ch * KC);
+            if (!(EXPF & 4)) ra.template store<BUF>(lraw, lds_sc + ch * KC, lds_sh + ch * KC, tid, lds_pw + ch * KC, lds_pb + ch * KC);
             __builtin_amdgcn_sched_barrier(0);
-            UA::issue(uw_n0, ulane, (unsigned)ch * slab_pitch + slab_n0, lu_addr, wave);
+            if (!(EXPF & 1)) UA::issue(uw_n0, ulane, (unsigned)ch * slab_pitch + slab_n0, lu_addr, wave);
             __builtin_amdgcn_sched_barrier(0);
-            const bool pf = ch + 2 < nch;
+            const bool pf = ch + 2 < nch && !(EXPF & 4);
             if (pf) ra.template load<BUF>(in_rsrc, (unsigned)((ch + 2) * KC * HW) * 4u, HW);
             __builtin_amdgcn_sched_barrier(0);
 #ifdef LASS_CONV_DIAG
@@ -386,6 +412,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
             const long long t3 = clock64();
 #endif
             // input transform V = B^T d B: one (channel, tile) item per thread and pass
+            if (!(EXPF & 2))
 #pragma unroll
             for (int it = 0; it < (KC * NWT) / NTHREADS; ++it) {
                 const int item = tid + it * NTHREADS;
@@ -429,7 +456,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
             const long long t5 = clock64();
 #endif
             // 16 GEMMs: M_xi += U_xi (32 couts x 8 cin) * V_xi (8 cin x 16 tiles)
-            gemm_steps<16, 256, 4 * VP>(afrag, bfrag, acc, [](int s) { return s; });
+            mfma_prio();
+            if (!(EXPF & 8)) gemm_steps<16, 256, 4 * VP>(afrag, bfrag, acc, [](int s) { return s; });
 #ifdef LASS_CONV_DIAG
             dg[0] += t1 - t0; dg[1] += t2 - t1; dg[2] += t3 - t2; dg[3] += t4 - t3; dg[4] += t5 - t4;
             dg[5] += clock64() - t5;
@@ -469,6 +497,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
         const v4i32 uw_n0 = make_rsrc_words(p.w2_wino, (unsigned)(4 * p.Cin2 * p.Nw) * 4u);
         for (int ch = 0; ch < nch; ++ch) {
             lds_barrier();  // previous chunk's MFMAs have finished reading V / U
+            prep_prio();
 #pragma unroll
             for (int it = 0; it < NITB; ++it) {
                 float2 r1 = rb[2 * it], r2 = rb[2 * it + 1];  // patch rows 1,2 x cols 1,2
@@ -495,6 +524,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
             else
                 wait_vmcnt<0>();
             lds_barrier();  // V visible, every wave's U rows landed
+            mfma_prio();
             gemm_steps<16, 256, 4 * VP>(afrag, bfrag, acc, [](int s) {
                 const int q = s / 4;                // 4 pair-steps (32 channels) per xi slot
                 return (q >> 1) * 4 + (q & 1) + 5;  // 5, 6, 9, 10
@@ -645,6 +675,10 @@ __global__ __launch_bounds__(256) void wino_shortcut_weights_kernel(const float*
 template <int FLAGS, bool PATCH>
 hipError_t launch_wino_v(const ConvArgs& p0, hipStream_t stream) {
     ConvArgs p = p0;
+#ifdef LASS_CONV_DIAG
+    static const int exp_flags = [] { const char* e = getenv("LASS_EXP"); return e ? atoi(e) : 0; }();
+    p.exp = exp_flags;
+#endif
     const bool wide = p.N % 64 == 0;
     if (p.W < 32) {  // 16- / 8-bin layers: 64-cout blocks of 8 x 16 or 16 x 8 output pixels
         if constexpr ((FLAGS & (F_MASK | F_PRECONV | F_RESPRE)) != 0) {
