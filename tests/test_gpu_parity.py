@@ -518,3 +518,35 @@ def test_bf16x3_split_mode_is_f32_accurate(synthetic_sd, oracle_sd, golden_dir):
     err = _rms(out.cpu() - torch.from_numpy(g["waveform"]))
     print("bf16x3 waveform RMS error vs the reference's own output", err, "relative", err / _rms(g["waveform"]))
     assert err < 1e-5, err
+
+
+def test_bf16_modes_full_size_metrics_vs_f32(synthetic_sd):
+    """BASELINE configs[2] at its stated size (B=16, 10 s @ 16 kHz): bf16 and bf16x3 waveforms against the f32 path on the
+    same inputs.  north_star's bar is SDR within +-0.05 dB; SDR / SDRi / SI-SDR of every clip (reference = the synthetic
+    source) must agree to that, and the split mode must stay inside the f32 tolerance class (1e-5 RMS)."""
+    from lass_amd.metrics import stats_to_db
+    from lass_amd.resunet import ResUNet30
+    B, L = 16, 160000
+    src, mix = synthetic.make_mixtures(4, L)
+    src = np.concatenate([src] * 4)[:B]
+    mix = np.concatenate([mix] * 4)[:B]
+    inp = {"mixture": torch.from_numpy(mix)[:, None, :].to(DEV), "condition": torch.from_numpy(synthetic.make_condition(B)).to(DEV)}
+    source = torch.from_numpy(src).to(DEV)
+    m = ResUNet30(1, 1, 512)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synthetic_sd.items()})
+    m = m.to(DEV).eval()
+    rows, outs = {}, {}
+    for mode in ("f32", "bf16", "bf16x3"):
+        out = m.set_compute_dtype(mode)(inp)["waveform"][:, 0].contiguous()
+        eng = m.engine
+        sdr, sisdr = stats_to_db(eng.sdr_stats(source, out).cpu().numpy(), L)
+        sdr0, _ = stats_to_db(eng.sdr_stats(source, inp["mixture"][:, 0].contiguous()).cpu().numpy(), L)
+        rows[mode] = np.stack([sdr, sdr - sdr0, sisdr], axis=1)
+        outs[mode] = out.cpu()
+    assert np.isfinite(rows["f32"]).all()
+    for mode in ("bf16", "bf16x3"):
+        d = np.abs(rows[mode] - rows["f32"]).max()
+        print(mode, "max |dB difference| vs f32 over 16 clips x (SDR, SDRi, SI-SDR):", d)
+        assert d < 0.05, (mode, d)
+    assert _rms(outs["bf16x3"] - outs["f32"]) <= 1e-5
+    assert 1e-6 < _rms(outs["bf16"] - outs["f32"]) < 5e-2 * _rms(outs["f32"])   # really the bf16 kernels, and sane
