@@ -1,12 +1,31 @@
-# Round-end profile set (run on the GPU box: `bash tools/profile_round.sh`); outputs under gpurun_out/prof_round/.
-#  1. rocprofv3 --kernel-trace --stats of the default bench (f32) and of --dtype bf16  -> kernel stats CSVs
-#  2. separate --pmc passes (FETCH_SIZE, WRITE_SIZE) of `bench.py --steps 1 --warmup 1` -> HBM traffic per conv launch
+# Round profile set (run on the GPU box: `bash tools/profile_round.sh`); outputs under gpurun_out/prof_round/, the
+# summaries to commit are copied into profiles/<round>/ by hand afterwards.
+#  1. rocprofv3 --kernel-trace --stats of the default bench (f32 headline + bf16 / bf16x3 modes in one run)
+#  2. separate --pmc passes (FETCH_SIZE, WRITE_SIZE) of `bench.py --steps 1 --warmup 1` for f32 and bf16
+#  3. FETCH_SIZE / WRITE_SIZE calibration of the access shapes the kernels use (tools/fetch_calib.hip)
+#  4. SQ counters per conv launch (tools/conv_bench.py, one iteration) for f32 and bf16 -> per-layer MFMA utilisation
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_round
 mkdir -p $O
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_f32 -o x -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_f32_under_rocprof.json 2> $O/stats_f32.log || exit 1
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_bf16 -o x -- python3 $R/bench.py --steps 5 --warmup 2 --dtype bf16 --no-cpu-baseline > $O/bench_bf16_under_rocprof.json 2> $O/stats_bf16.log || exit 1
-timeout -k 10 120 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o x -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/pmc_fetch.json 2> $O/pmc_fetch.log || exit 1
-timeout -k 10 120 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o x -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/pmc_write.json 2> $O/pmc_write.log || exit 1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o x -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats.log || exit 1
+for D in f32 bf16; do
+  timeout -k 10 150 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_$D -o x -- python3 $R/bench.py --steps 1 --warmup 1 --dtype $D --modes none --no-cpu-baseline > $O/pmc_fetch_$D.json 2> $O/pmc_fetch_$D.log || exit 1
+  timeout -k 10 150 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_$D -o x -- python3 $R/bench.py --steps 1 --warmup 1 --dtype $D --modes none --no-cpu-baseline > $O/pmc_write_$D.json 2> $O/pmc_write_$D.log || exit 1
+done
+hipcc -O3 --offload-arch=gfx950 $R/tools/fetch_calib.hip -o $O/fetch_calib 2>/dev/null || exit 1
+timeout -k 10 120 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/calib_fetch -o x -- $O/fetch_calib > $O/calib_fetch.log 2>&1 || exit 1
+timeout -k 10 120 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/calib_write -o x -- $O/fetch_calib > $O/calib_write.log 2>&1 || exit 1
+for D in f32 bf16; do
+  LASS_COMPUTE=$D timeout -k 10 150 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d $O/pmc_sq_$D -o x -- python3 $R/tools/conv_bench.py --iters 1 > $O/pmc_sq_$D.log 2>&1 || exit 1
+done
+cd $R
+F=$(find $O/calib_fetch -name '*counter_collection.csv'); W=$(find $O/calib_write -name '*counter_collection.csv')
+python3 tools/fetch_calib_summary.py $F $W $O/fetch_calibration.json > /dev/null
+for D in f32 bf16; do
+  python3 tools/traffic_summary.py $(find $O/pmc_fetch_$D -name '*counter_collection.csv') $(find $O/pmc_write_$D -name '*counter_collection.csv') $O/conv_traffic_$D.json $D $O/fetch_calibration.json
+  python3 tools/pmc_table.py $(find $O/pmc_sq_$D -name '*counter_collection.csv') $D > $O/mfma_util_$D.md
+  cat $O/mfma_util_$D.md
+done
+cp $(find $O/stats -name '*kernel_stats.csv') $O/kernel_stats.csv
 echo done

@@ -1,39 +1,64 @@
 #!/usr/bin/env python3
-"""Fold rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs of `bench.py --steps 1 --warmup 1`) into
-profiles/<round>/conv_traffic.json: HBM bytes per launch of the dominant kernel class (conv3x3_mfma), last step only.
+"""Fold rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs of `bench.py --steps 1 --warmup 1 --modes none`)
+into profiles/<round>/conv_traffic_<dtype>.json: HBM-side bytes per launch of the dominant kernel class (conv3x3_mfma:
+the 26 Winograd / bf16 3x3 launches of a step), last step only.
 
-gfx950 corrections (MI355X_MICROARCH.md §HBM): FETCH_SIZE / WRITE_SIZE are in KiB-units of 1024 B; FETCH_SIZE reads
-exactly 1/2 of the bytes of a wide (16 B/lane) coalesced stream - our conv kernels read 4 B/lane (activations) and
-16 B/lane (weights), an access mix the guide calls uncalibrated, so both the raw and the x2-corrected figure are kept.
-"""
-import csv, json, sys, collections
+gfx950 corrections (MI355X_MICROARCH.md, HBM): both counters are in units of 1024 B; FETCH_SIZE reports exactly 1/2 of
+the bytes read.  tools/fetch_calib.hip measured that factor for every access shape these kernels use (4 / 8 / 16 B per
+lane buffer loads, 128-byte row segments, LDS-DMA): 0.5000 in all cases, WRITE_SIZE 1.000 (profiles/r02/
+fetch_calibration.json) - so ONE corrected number is reported: traffic = FETCH_SIZE / 0.5 + WRITE_SIZE.
+Usage: traffic_summary.py fetch.csv write.csv out.json dtype [fetch_calibration.json]"""
+import collections
+import csv
+import json
+import sys
+
 
 def per_dispatch(path, counter):
     d = collections.OrderedDict()
     for r in csv.DictReader(open(path)):
-        if r['Counter_Name'] != counter: continue
-        k = int(r['Dispatch_Id'])
-        e = d.setdefault(k, {'name': r['Kernel_Name'], 'v': 0.0})
+        if r['Counter_Name'] != counter:
+            continue
+        e = d.setdefault(int(r['Dispatch_Id']), {'name': r['Kernel_Name'], 'v': 0.0})
         e['v'] += float(r['Counter_Value'])
     return list(d.values())
 
-def main(fetch_csv, write_csv, out_json, launches_per_step=26):
-    f = [e for e in per_dispatch(fetch_csv, 'FETCH_SIZE') if (('conv_kernel' in e['name'] and '<1,' not in e['name'] and 'ILi1E' not in e['name']) or 'wino_kernel' in e['name'])]
-    w = [e for e in per_dispatch(write_csv, 'WRITE_SIZE') if (('conv_kernel' in e['name'] and '<1,' not in e['name'] and 'ILi1E' not in e['name']) or 'wino_kernel' in e['name'])]
-    f, w = f[-launches_per_step:], w[-launches_per_step:]
-    fetch = sum(e['v'] for e in f) * 1024.0
-    write = sum(e['v'] for e in w) * 1024.0
+
+def is_conv3x3(name):
+    if 'wino_kernel' in name:
+        return True
+    if 'conv_bf16_kernel<9' in name or 'conv_bf16_kernelILi9E' in name:
+        return True
+    return ('conv_kernel' in name) and 'relayout' not in name and ('<9,' in name or 'ILi9E' in name)
+
+
+def main(fetch_csv, write_csv, out_json, dtype, calib_json=None, launches_per_step=26):
+    ratio_f, ratio_w = 0.5, 1.0
+    calib = None
+    if calib_json:
+        calib = json.load(open(calib_json))
+        rf = list(calib['fetch_ratio'].values())
+        rw = list(calib['write_ratio'].values())
+        assert max(rf) - min(rf) < 1e-3 and max(rw) - min(rw) < 1e-3, "access shapes disagree: per-kernel factors needed"
+        ratio_f, ratio_w = sum(rf) / len(rf), sum(rw) / len(rw)
+    f = [e for e in per_dispatch(fetch_csv, 'FETCH_SIZE') if is_conv3x3(e['name'])][-launches_per_step:]
+    w = [e for e in per_dispatch(write_csv, 'WRITE_SIZE') if is_conv3x3(e['name'])][-launches_per_step:]
+    assert len(f) == launches_per_step and len(w) == launches_per_step, (len(f), len(w))
+    fetch = sum(e['v'] for e in f) * 1024.0 / ratio_f
+    write = sum(e['v'] for e in w) * 1024.0 / ratio_w
     res = {
-        "kernel_class": "conv3x3_mfma", "launches": launches_per_step,
-        "fetch_bytes_raw_per_launch": fetch / launches_per_step,
-        "fetch_bytes_x2_per_launch": 2 * fetch / launches_per_step,
+        "kernel_class": "conv3x3_mfma", "dtype": dtype, "launches": launches_per_step,
+        "fetch_bytes_per_launch": fetch / launches_per_step,
         "write_bytes_per_launch": write / launches_per_step,
-        "traffic_bytes_per_launch": (2 * fetch + write) / launches_per_step,
-        "traffic_bytes_per_launch_raw": (fetch + write) / launches_per_step,
-        "note": "FETCH_SIZE x2 per the gfx950 correction for coalesced streams; raw kept because 4-B/lane loads are uncalibrated",
+        "traffic_bytes_per_launch": (fetch + write) / launches_per_step,
+        "fetch_calibration": {"fetch_ratio": ratio_f, "write_ratio": ratio_w,
+                              "source": calib_json or "MI355X_MICROARCH.md (0.5 / 1.0)"},
+        "workload": "bench.py --steps 1 --warmup 1 (B=16, 10 s clips), last step",
+        "note": "L2 memory-side request bytes (Infinity-Cache hits included), corrected by the measured counter ratio",
     }
     json.dump(res, open(out_json, 'w'), indent=1)
     print(json.dumps(res))
 
+
 if __name__ == '__main__':
-    main(*sys.argv[1:4])
+    main(*sys.argv[1:6])
