@@ -52,10 +52,16 @@ struct Phase16 {
     unsigned woff[NWLD]; // BYTE offset of this thread's 16-B weight units inside a chunk's slab
     unsigned okbits;
     unsigned dvo[DMA ? NPC : 1];  // DMA: byte offset of this lane's unit in piece wave + 4*i (0xC0000000 = zero fill)
+    // DMA kernels stage the weight slab by LDS-DMA too: rows (tap, octet) of NT couts x 16 B; a 1-KiB piece is RPP rows
+    static constexpr int RPP = 64 / NT;            // 1 (64-cout tiles) or 2 (32-cout tiles)
+    static constexpr int NWPIECE = W1_U4 / 64;     // pieces per plane (hi or lo): 18 / 9 (3x3), 2 / 1 (1x1)
+    static_assert(W1_U4 % 64 == 0, "whole pieces");
+    static constexpr int NWPC = (NWPIECE + 3) / 4; // pieces per wave
+    unsigned wvo;                                  // this lane's byte offset inside a weight piece's source rows
     float v[(PRE || DMA) ? 1 : 2][(PRE || DMA) ? 1 : NPP][(PRE || DMA) ? 1 : 8];  // prefetched f32 activations: [octet][pass][channel in octet]
     float x0v[PRE ? NPP : 1];        // PRE: x0 at this thread's pixels
     float pcw[PRE ? KB : 1], pcb[PRE ? KB : 1];  // PRE: pre_conv weight / bias of the prefetched chunk's channels
-    uint4 wv[SPLIT][NWLD];  // prefetched bf16 weights (hi, lo)
+    uint4 wv[DMA ? 1 : SPLIT][DMA ? 1 : NWLD];  // prefetched bf16 weights (hi, lo); DMA kernels: unused
     float psc[KB], psh[KB];
 
     __device__ __forceinline__ static int upos(int tid, int k) {
@@ -93,6 +99,22 @@ struct Phase16 {
             const bool ok = e < 2 * NPIX && gy >= 0 && gy < H && gx >= 0 && gx < W;
             // 0xC0000000: beyond any descriptor -> zero fill (padding); 0xFFFFFFFF: lane past the image -> not issued
             dvo[i] = ok ? 16u * (unsigned)((o * H + gy) * W + gx) : (e < 2 * NPIX ? 0xC0000000u : 0xFFFFFFFFu);
+        }
+    }
+    __device__ __forceinline__ void init_wdma(int lane, int Cout) {
+        wvo = 16u * (unsigned)((lane / NT) * Cout + lane % NT);
+    }
+    // w_rs / wl_rs: weight matrix (hi / lo) from column n0 on; wb: byte offset of the chunk's slab [tap][octet][Cout];
+    // wl_addr: LDS byte address of the weight buffer to fill
+    __device__ __forceinline__ void issue_wdma(v4i32 w_rs, v4i32 wl_rs, unsigned wb, int Cout, unsigned wl_addr, int wave) {
+#pragma unroll
+        for (int i = 0; i < NWPC; ++i) {
+            const int piece = wave + 4 * i;  // wave-uniform
+            if (piece < NWPIECE) {
+                const unsigned soff = wb + (unsigned)(piece * RPP * Cout) * 16u;
+                lds_dma_16B(w_rs, wvo, soff, wl_addr + (unsigned)piece * 1024u);
+                if (SPLIT == 2) lds_dma_16B(wl_rs, wvo, soff, wl_addr + (unsigned)(W1_U4 * 16) + (unsigned)piece * 1024u);
+            }
         }
     }
     // rs / rs_lo: descriptors of this clip's blocked bf16 planes; soff: byte offset of the chunk's first octet;
@@ -134,7 +156,7 @@ struct Phase16 {
             }
         }
 #pragma unroll
-        for (int i = 0; i < NWLD; ++i) {
+        for (int i = 0; i < (DMA ? 0 : NWLD); ++i) {
             wv[0][i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(w_rs, (int)woff[i], (int)wb, 0));
             if (SPLIT == 2)
                 wv[1][i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wl_rs, (int)woff[i], (int)wb, 0));
@@ -213,7 +235,10 @@ struct Phase16 {
             }
             return;
         }
-        bf16x8 a[2][NCO], b[2][NPX];
+        // fragments of tap + PFD are read before the MFMAs of tap (pinned): PFD taps = PFD * NCO * NPX MFMAs of cover for
+        // the LDS latency
+        constexpr int PFD = TAPS > 2 ? 2 : 1;
+        bf16x8 a[PFD + 1][NCO], b[PFD + 1][NPX];
         auto rd = [&](int tap, bf16x8 (&aa)[NCO], bf16x8 (&bb)[NPX]) {
 #pragma unroll
             for (int co = 0; co < NCO; ++co) aa[co] = abase[tap * 2 * NT + co * 32];
@@ -221,17 +246,18 @@ struct Phase16 {
             for (int px = 0; px < NPX; ++px)
                 bb[px] = bbase[(px * PH + (TAPS == 9 ? tap / 3 : 0)) * IP + (TAPS == 9 ? tap % 3 : 0)];
         };
-        rd(0, a[0], b[0]);
+#pragma unroll
+        for (int t = 0; t < PFD && t < TAPS; ++t) rd(t, a[t], b[t]);
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
-            if (tap + 1 < TAPS) rd(tap + 1, a[(tap + 1) & 1], b[(tap + 1) & 1]);
+            if (tap + PFD < TAPS) rd(tap + PFD, a[(tap + PFD) % (PFD + 1)], b[(tap + PFD) % (PFD + 1)]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int co = 0; co < NCO; ++co)
 #pragma unroll
                 for (int px = 0; px < NPX; ++px)
-                    acc[co][px] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tap & 1][co], b[tap & 1][px], acc[co][px],
-                                                                          0, 0, 0);
+                    acc[co][px] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tap % (PFD + 1)][co], b[tap % (PFD + 1)][px],
+                                                                          acc[co][px], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -257,8 +283,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
     using PA = Phase16<TAPS, NCO, NPX, PW, PRO, SPLIT, PRE, INBF>;
     constexpr bool IN2BF = (FLAGS & F_IN2BF16) != 0;  // phase B reads the blocked bf16 raw copy by LDS-DMA
     using PB = Phase16<1, NCO, NPX, PW, false, SPLIT, false, IN2BF>;
-    constexpr int PA_LDS = INBF ? 2 * PA::IN_U4 + PA::W_U4 : PA::LDS_U4;  // INBF: two image buffers + one weight region
-    constexpr int PB_LDS = IN2BF ? 2 * PB::IN_U4 + PB::W_U4 : PB::LDS_U4;
+    constexpr int PA_LDS = INBF ? 2 * PA::IN_U4 + 2 * PA::W_U4 : PA::LDS_U4;  // INBF: image and weights double-buffered
+    constexpr int PB_LDS = IN2BF ? 2 * PB::IN_U4 + 2 * PB::W_U4 : PB::LDS_U4;
     constexpr int LDS_U4 = HASB ? MaxU<PA_LDS, PB_LDS>::v : PA_LDS;
     constexpr int PH = PA::PH, WROWS = PA::WROWS, PHT = PA::PHT, NT = PA::NT;
     constexpr bool MASK = (FLAGS & F_MASK) != 0;
@@ -336,7 +362,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
         pb.load(in2_rs, (unsigned)(c * KB * HW) * 4u, HW, wb_rs, wbl_rs, (unsigned)(c * 2 * p.Nw) * 16u, nullptr, nullptr);
     };
 
-    uint4* wl_a = lds4 + (INBF ? 2 * PA::IN_U4 : PA::IN_U4);  // weight region of phase A
+    uint4* wl_a = lds4 + PA::IN_U4;  // weight region of phase A (register-staged kernels)
     pa.init_w(tid, p.Nw);
     f32x16 acc[NCO][NPX];
     auto init_acc = [&]() {
@@ -349,36 +375,34 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
                     acc[co][px][r] = BIAS ? lds_bias[co * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf] : 0.f;
     };
     if (INBF) {
-        // image of chunk ch+1 lands in the other buffer by LDS-DMA while chunk ch is contracted; weights go through
-        // registers into the single weight region between the two barriers
+        // Everything a chunk needs - the activation image and the weight slab - arrives by LDS-DMA into alternating
+        // buffers while the previous chunk is contracted: no VGPRs, no VALU, no ds_write, ONE barrier per chunk.
         const long plane = (long)(p.Cin / 8) * HW * 16;  // bytes of one clip in the blocked layout
         const v4i32 a_rs = make_rsrc_words(reinterpret_cast<const char*>(p.in_bf16) + (size_t)b * plane, (unsigned)plane);
         const v4i32 al_rs = SPLIT == 2
                                 ? make_rsrc_words(reinterpret_cast<const char*>(p.in_bf16_lo) + (size_t)b * plane, (unsigned)plane)
                                 : a_rs;
+        const unsigned wbytes = (unsigned)(((long)(p.Cin / KB) * TAPS * 2 * p.Nw - n0) * 16);
+        const v4i32 wd_rs = make_rsrc_words(wa, wbytes);
+        const v4i32 wdl_rs = SPLIT == 2 ? make_rsrc_words(wa_lo, wbytes) : wd_rs;
         const unsigned img0 = (unsigned)(size_t)(__attribute__((address_space(3))) uint4*)lds4;
-        const unsigned img1 = img0 + (unsigned)(PA::IN_U4 * 16);
+        const unsigned wl0 = img0 + (unsigned)(2 * PA::IN_U4 * 16);
         pa.init_dma(lane, wave, y0, x0, p.H, p.W);
+        pa.init_wdma(lane, p.Nw);
         pa.issue_dma(a_rs, al_rs, 0u, img0, wave);
-        loadA(0);
+        pa.issue_wdma(wd_rs, wdl_rs, 0u, p.Nw, wl0, wave);
         __syncthreads();  // epilogue tables visible
-        pa.store(lds4, wl_a, tid);
-        wait_vmcnt<0>();
-        __syncthreads();
         init_acc();
         for (int ch = 0; ch < nA; ++ch) {
-            const bool more = ch + 1 < nA;
-            if (more) {
-                pa.issue_dma(a_rs, al_rs, (unsigned)((ch + 1) * 2 * HW) * 16u, (ch & 1) ? img0 : img1, wave);
-                loadA(ch + 1);
+            const int cur = ch & 1;
+            wait_vmcnt<0>();   // this wave's pieces of chunk ch have landed
+            __syncthreads();   // ... everyone's have, and everyone has finished contracting chunk ch-1
+            if (ch + 1 < nA) {
+                pa.issue_dma(a_rs, al_rs, (unsigned)((ch + 1) * 2 * HW) * 16u, img0 + (unsigned)((cur ^ 1) * PA::IN_U4 * 16), wave);
+                pa.issue_wdma(wd_rs, wdl_rs, (unsigned)((ch + 1) * TAPS * 2 * p.Nw) * 16u, p.Nw,
+                              wl0 + (unsigned)((cur ^ 1) * PA::W_U4 * 16), wave);
             }
-            PA::compute(lds4 + ((ch & 1) ? PA::IN_U4 : 0), wl_a, acc, lane, wave);
-            __syncthreads();
-            if (more) {
-                pa.store(lds4, wl_a, tid);
-                wait_vmcnt<0>();
-            }
-            __syncthreads();
+            PA::compute(lds4 + cur * PA::IN_U4, lds4 + 2 * PA::IN_U4 + cur * PA::W_U4, acc, lane, wave);
         }
     } else {
         pa.init(tid, y0, x0, p.H, p.W);
@@ -422,32 +446,29 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
     }
     if (!INBF) PA::compute(lds4, wl_a, acc, lane, wave);  // last chunk of phase A (the INBF loop contracts all of them)
     if (HASB && IN2BF) {
-        // same schedule as the INBF main phase: image by LDS-DMA into alternating buffers, weights through registers
-        uint4* wl_b = lds4 + 2 * PB::IN_U4;
+        // same schedule as the INBF main phase: image and weights by LDS-DMA into alternating buffers
         const long plane2 = (long)(p.Cin2 / 8) * HW * 16;
         const v4i32 r_rs = make_rsrc_words(reinterpret_cast<const char*>(p.in2_bf16) + (size_t)b * plane2, (unsigned)plane2);
+        const unsigned wbytes2 = (unsigned)(((long)(p.Cin2 / KB) * 2 * p.Nw - n0) * 16);
+        const v4i32 wd_rs = make_rsrc_words(wb2, wbytes2);
+        const v4i32 wdl_rs = SPLIT == 2 ? make_rsrc_words(wb2_lo, wbytes2) : wd_rs;
         const unsigned img0 = (unsigned)(size_t)(__attribute__((address_space(3))) uint4*)lds4;
-        const unsigned img1 = img0 + (unsigned)(PB::IN_U4 * 16);
+        const unsigned wl0 = img0 + (unsigned)(2 * PB::IN_U4 * 16);
         pb.init_dma(lane, wave, y0, x0, p.H, p.W);
+        pb.init_wdma(lane, p.Nw);
         __syncthreads();  // phase A has finished with the LDS
         pb.issue_dma(r_rs, r_rs, 0u, img0, wave);
-        loadB(0);
-        pb.store(lds4, wl_b, tid);
-        wait_vmcnt<0>();
-        __syncthreads();
+        pb.issue_wdma(wd_rs, wdl_rs, 0u, p.Nw, wl0, wave);
         for (int ch = 0; ch < nB; ++ch) {
-            const bool more = ch + 1 < nB;
-            if (more) {
-                pb.issue_dma(r_rs, r_rs, (unsigned)((ch + 1) * 2 * HW) * 16u, (ch & 1) ? img0 : img1, wave);
-                loadB(ch + 1);
-            }
-            PB::compute(lds4 + ((ch & 1) ? PB::IN_U4 : 0), wl_b, acc, lane, wave);
+            const int cur = ch & 1;
+            wait_vmcnt<0>();
             __syncthreads();
-            if (more) {
-                pb.store(lds4, wl_b, tid);
-                wait_vmcnt<0>();
+            if (ch + 1 < nB) {
+                pb.issue_dma(r_rs, r_rs, (unsigned)((ch + 1) * 2 * HW) * 16u, img0 + (unsigned)((cur ^ 1) * PB::IN_U4 * 16), wave);
+                pb.issue_wdma(wd_rs, wdl_rs, (unsigned)((ch + 1) * 2 * p.Nw) * 16u, p.Nw,
+                              wl0 + (unsigned)((cur ^ 1) * PB::W_U4 * 16), wave);
             }
-            __syncthreads();
+            PB::compute(lds4 + cur * PB::IN_U4, lds4 + 2 * PB::IN_U4 + cur * PB::W_U4, acc, lane, wave);
         }
     } else if (HASB) {
         uint4* wl_b = lds4 + PB::IN_U4;
@@ -509,12 +530,34 @@ hipError_t launch_bf16_one(const ConvArgs& p, hipStream_t stream) {
 template <int TAPS, int FLAGS>
 hipError_t launch_bf16(const ConvArgs& p, hipStream_t stream) {
     const int pw = p.W >= 32 ? 32 : p.W;
+    constexpr bool NARROW = (FLAGS & (F_MASK | F_RESPRE | F_PRECONV)) != 0;  // 32-cout-only kernels (host-checked N == 32)
+    if constexpr (NARROW) {
+        if (pw != 32 || p.N != 32) return hipErrorInvalidValue;
+        if constexpr ((FLAGS & F_INBF16) != 0) {
+            static const int force = [] { const char* e = getenv("LASS_BF16_NPX"); return e ? atoi(e) : 0; }();
+            if (force == 4) return launch_bf16_one<TAPS, 1, 4, 32, FLAGS>(p, stream);
+        }
+        return launch_bf16_one<TAPS, 1, 2, 32, FLAGS>(p, stream);
+    } else
     if (pw == 32) {
+        if constexpr ((FLAGS & F_INBF16) != 0) {
+            // DMA-fed kernels: 16-row tiles (each wave 4 px-tiles x NCO cout-tiles: 0.75 instead of 1 fragment read per
+            // MFMA, the weight slab shared by twice the pixels) wherever that still leaves >= 2 workgroups per CU slot
+            const long wgs16 = (long)(p.W / 32) * ((p.H + 15) / 16) * (p.N / (p.N % 64 == 0 ? 64 : 32)) * p.B;
+            static const int force = [] { const char* e = getenv("LASS_BF16_NPX"); return e ? atoi(e) : 0; }();
+            (void)wgs16;
+            if (force == 4) {  // measured r2: 16-row tiles lose 15-20 % on every layer (occupancy beats LDS traffic)
+                if (p.N % 64 == 0) return launch_bf16_one<TAPS, 2, 4, 32, FLAGS>(p, stream);
+                return launch_bf16_one<TAPS, 1, 4, 32, FLAGS>(p, stream);
+            }
+        }
         if (p.N % 64 == 0) return launch_bf16_one<TAPS, 2, 2, 32, FLAGS>(p, stream);
         return launch_bf16_one<TAPS, 1, 2, 32, FLAGS>(p, stream);
     }
-    if (pw == 16) return launch_bf16_one<TAPS, 1, 1, 16, FLAGS>(p, stream);
-    if (pw == 8) return launch_bf16_one<TAPS, 1, 2, 8, FLAGS>(p, stream);
+    if constexpr (!NARROW) {
+        if (pw == 16) return launch_bf16_one<TAPS, 1, 1, 16, FLAGS>(p, stream);
+        if (pw == 8) return launch_bf16_one<TAPS, 1, 2, 8, FLAGS>(p, stream);
+    }
     return hipErrorInvalidValue;
 }
 
@@ -549,9 +592,8 @@ hipError_t lass_launch_conv_bf16(ConvKind kind, const ConvArgs& p, hipStream_t s
                 if (p.N != 32 || p.W + 1 != p.mask_nbins || !p.in_bf16 || !p.mask_w || !p.mask_b || !p.mask_mag || !p.mask_cos ||
                     !p.mask_sin || !p.mask_im || p.mask_T <= 0 || p.mask_T > p.H)
                     return hipErrorInvalidValue;
-                if (p.in2_bf16)
-                    return launch_bf16_one<9, 1, 2, 32, F_PHASEB | F_BIAS | F_INBF16 | F_IN2BF16 | F_MASK | F_NOSPLIT>(p, stream);
-                return launch_bf16_one<9, 1, 2, 32, F_PHASEB | F_BIAS | F_INBF16 | F_MASK>(p, stream);
+                if (p.in2_bf16) return launch_bf16<9, F_PHASEB | F_BIAS | F_INBF16 | F_IN2BF16 | F_MASK | F_NOSPLIT>(p, stream);
+                return launch_bf16<9, F_PHASEB | F_BIAS | F_INBF16 | F_MASK>(p, stream);
             }
             if (p.in_bf16 && p.out_bf16 && !p.out_bf16_act) {
                 // decoder output handed to the next transposed conv as ONE activated blocked bf16 tensor (its BN+FiLM+leaky
@@ -581,9 +623,8 @@ hipError_t lass_launch_conv_bf16(ConvKind kind, const ConvArgs& p, hipStream_t s
             return launch_bf16_one<9, 1, 2, 32, F_PRO | F_EPIACT | F_PRECONV>(p, stream);
         case CONV2_IDENT_PRE:
             if (!p.res || !p.pre_w || !p.pre_b || p.N != 32 || p.W % 32 != 0) return hipErrorInvalidValue;
-            if (p.in_bf16 && p.out_bf16)
-                return launch_bf16_one<9, 1, 2, 32, F_RES | F_RESPRE | F_INBF16 | F_OUTBF16 | F_NOSPLIT>(p, stream);
-            if (p.in_bf16) return launch_bf16_one<9, 1, 2, 32, F_RES | F_RESPRE | F_INBF16>(p, stream);
+            if (p.in_bf16 && p.out_bf16) return launch_bf16<9, F_RES | F_RESPRE | F_INBF16 | F_OUTBF16 | F_NOSPLIT>(p, stream);
+            if (p.in_bf16) return launch_bf16<9, F_RES | F_RESPRE | F_INBF16>(p, stream);
             return launch_bf16_one<9, 1, 2, 32, F_RES | F_RESPRE>(p, stream);
         default:
             return hipErrorInvalidValue;

@@ -181,17 +181,19 @@ __device__ __forceinline__ void store_tile(const ConvArgs& p, f32x16 (&acc)[NCO]
         if (p.pool_out || p.pool_bf16) {  // wave-uniform
             const int Wo = p.W / 2;
             if (p.pool_h == 2) {
-                if (PW == 32 && NPX == 2) {
-                    const int y = y0 + wave * WROWS;  // even row of the pair (px-tile 0); px-tile 1 is y+1
+                if (PW == 32 && NPX % 2 == 0)
+#pragma unroll
+                for (int pp = 0; pp < NPX / 2; ++pp) {  // row pairs (px-tiles 2pp, 2pp+1) of this wave
+                    const int y = y0 + wave * WROWS + 2 * pp;  // even row of the pair
                     const int Ho = p.H / 2;
                     float* dst = p.pool_out + (size_t)b * (p.pool_bs ? (size_t)p.pool_bs : (size_t)p.N * Ho * Wo) + (size_t)(n0 + co * 32 + 4 * khalf) * Ho * Wo +
                                  (size_t)(y >> 1) * Wo + (x >> 1);
                     float pooled[16];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const float o0 = __shfl_xor(val[0][r], 1, 64), o1 = __shfl_xor(val[NPX - 1][r], 1, 64);
-                        float sum = val[0][r] + o0;
-                        sum += val[NPX - 1][r];
+                        const float o0 = __shfl_xor(val[2 * pp][r], 1, 64), o1 = __shfl_xor(val[2 * pp + 1][r], 1, 64);
+                        float sum = val[2 * pp][r] + o0;
+                        sum += val[2 * pp + 1][r];
                         sum += o1;
                         pooled[r] = sum * 0.25f;
                     }
