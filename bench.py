@@ -311,6 +311,7 @@ def main():
     else:
         exch["error"] = pg_error
 
+    graph_on, graph_caps, graph_replays = eng.graph_stats()
     psteps = max(1, min(args.profile_steps, args.steps))
     prof = profiled(eng, psteps)
 
@@ -372,6 +373,9 @@ def main():
                        "clips_per_gpu_per_step": B, "samples_per_clip": L, "parallelism": f"clip-sharded x{world}"},
             "realtime_factor": world * B * args.steps / dt * (L / 16000.0),
             "exchange": exch,
+            "launch": {"hipgraph_replay": graph_on, "captures": graph_caps, "replays_in_headline_loops": graph_replays,
+                       "note": "the timed loop replays ONE captured hipGraph of the ~40 launches per step; the profiled "
+                               "loop (HIP events per kernel class) runs eagerly"},
             "roofline": {"bound": "mfma", "kernel": kernel,
                          "achieved": head["executed_tflops"], "peak": head["peak_tflops"], "unit": "TFLOP/s",
                          "frac": head["frac"],

@@ -3,7 +3,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_double, c_int, c_int64, c_size_t, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_int, c_int64, c_long, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LASS_HIP_LIB") or os.path.join(_HERE, "csrc", "liblass_hip.so")  # env: diagnostic builds
@@ -26,6 +26,7 @@ SYMBOLS = [
     ("lass_mix_at_snr", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     ("lass_multi_stft", c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, POINTER(c_int), POINTER(c_void_p),
                                 POINTER(c_void_p), POINTER(c_void_p), c_void_p]),
+    ("lass_graph_stats", c_int, [c_void_p, POINTER(c_long), POINTER(c_long)]),
     ("lass_separate_components", c_int, [c_void_p, POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                          c_int, c_void_p, c_size_t, c_void_p]),
     ("lass_stft_components", c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, POINTER(c_int),

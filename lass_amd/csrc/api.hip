@@ -107,6 +107,22 @@ struct lass_ctx {
     bool fuse_pool = true;  // LASS_FUSE_POOL=0 selects the stand-alone pool kernel (A/B + parity of both paths)
     bool fuse_catb = true;  // bf16 mode: decoder concats as blocked bf16 copies (LASS_FUSE_CATB=0: f32 concat)
     bool fuse_mask = true;  // LASS_FUSE_MASK=0 keeps after_conv + mask as their own kernel behind decoder_block6
+    // hipGraph replay of lass_separate (LASS_GRAPH=0 disables): the ~40 launches of one (pointers, shape) combination are
+    // captured once on an internal stream and replayed on the caller's stream
+    bool use_graph = true;
+    struct GraphKey {
+        const void *mix = nullptr, *cond = nullptr, *out = nullptr, *ws = nullptr;
+        int B = 0, L = 0;
+        unsigned long gen = 0;
+        bool operator==(const GraphKey& o) const {
+            return mix == o.mix && cond == o.cond && out == o.out && ws == o.ws && B == o.B && L == o.L && gen == o.gen;
+        }
+    };
+    GraphKey g_key, g_seen;        // key of the instantiated graph / of the previous call
+    hipGraphExec_t g_exec = nullptr;
+    hipStream_t g_stream = nullptr;
+    unsigned long gen = 0;         // bumped by lass_finalize: a graph holds weight pointers
+    long g_replays = 0, g_captures = 0;
     bool profiling = false;
     std::vector<ProfEntry> prof;
     std::vector<hipEvent_t> ev_pool;
@@ -612,6 +628,7 @@ static int create_impl(lass_ctx** out, int device_id, const Geometry& geom) {
     if (const char* e = getenv("LASS_FUSE_MASK")) c->fuse_mask = atoi(e) != 0;
     if (const char* e = getenv("LASS_FUSE_CATB")) c->fuse_catb = atoi(e) != 0;
     if (const char* e = getenv("LASS_FUSE_PRECONV")) c->fuse_preconv = atoi(e) != 0;
+    if (const char* e = getenv("LASS_GRAPH")) c->use_graph = atoi(e) != 0;
     c->prof.resize(P_COUNT);
     for (int i = 0; i < P_COUNT; ++i) c->prof[i].name = kProfNames[i];
     build_arch(c);
@@ -677,6 +694,8 @@ int lass_destroy(lass_ctx* c) {
     free_owned(c);
     for (auto& kv : c->raw) (void)hipFree(kv.second.d);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    if (c->g_exec) (void)hipGraphExecDestroy(c->g_exec);
+    if (c->g_stream) (void)hipStreamDestroy(c->g_stream);
     (void)hipFree(c->tw2k);
     delete c;
     return 0;
@@ -835,6 +854,7 @@ int lass_finalize(lass_ctx* c, int compute_mode) {
     }
     HIP_TRY(c, hipStreamSynchronize(st));
     c->finalized = true;
+    ++c->gen;  // any captured graph refers to the previous derived buffers
     return 0;
 }
 
@@ -1249,8 +1269,56 @@ static int separate_impl(lass_ctx* c, const float* mixture, const Components* co
 
 int lass_separate(lass_ctx* c, const float* mixture, const float* condition, float* out, int B, int L, void* workspace,
                   size_t workspace_bytes, void* stream) {
+    if (!c) return LASS_ERR_ARG;
     if (!mixture) return fail(c, LASS_ERR_ARG, "lass_separate: null pointer");
+    // Graph replay: a call whose pointers and shape equal the PREVIOUS call's is captured once (on an internal stream; the
+    // caller's may be the legacy default stream, which cannot be captured) and replayed from then on.  Callers that hand
+    // over fresh buffers every time (the evaluator loop) simply stay on the eager path; so does a profiled context.
+    lass_ctx::GraphKey key;
+    key.mix = mixture; key.cond = condition; key.out = out; key.ws = workspace; key.B = B; key.L = L; key.gen = c->gen;
+    if (c->use_graph && !c->profiling && c->finalized) {
+        if (c->g_exec && key == c->g_key) {
+            HIP_TRY(c, hipSetDevice(c->device));
+            HIP_TRY(c, hipGraphLaunch(c->g_exec, (hipStream_t)stream));
+            ++c->g_replays;
+            return 0;
+        }
+        if (key == c->g_seen) {  // second identical call in a row: worth a capture
+            HIP_TRY(c, hipSetDevice(c->device));
+            if (!c->g_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->g_stream, hipStreamNonBlocking));
+            if (c->g_exec) { (void)hipGraphExecDestroy(c->g_exec); c->g_exec = nullptr; }
+            if (hipStreamBeginCapture(c->g_stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                const int r = separate_impl(c, mixture, nullptr, condition, out, B, L, workspace, workspace_bytes, c->g_stream,
+                                            "lass_separate");
+                hipGraph_t graph = nullptr;
+                const hipError_t e = hipStreamEndCapture(c->g_stream, &graph);
+                if (r) { if (graph) (void)hipGraphDestroy(graph); return r; }
+                if (e == hipSuccess && graph && hipGraphInstantiate(&c->g_exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+                    (void)hipGraphDestroy(graph);
+                    c->g_key = key;
+                    ++c->g_captures;
+                    HIP_TRY(c, hipGraphLaunch(c->g_exec, (hipStream_t)stream));
+                    return 0;
+                }
+                if (graph) (void)hipGraphDestroy(graph);
+                c->g_exec = nullptr;
+                (void)hipGetLastError();
+                c->use_graph = false;  // capture is not usable here: stay eager from now on
+            } else {
+                (void)hipGetLastError();
+                c->use_graph = false;
+            }
+        }
+    }
+    c->g_seen = key;
     return separate_impl(c, mixture, nullptr, condition, out, B, L, workspace, workspace_bytes, stream, "lass_separate");
+}
+
+int lass_graph_stats(const lass_ctx* c, long* captures, long* replays) {
+    if (!c) return LASS_ERR_ARG;
+    if (captures) *captures = c->g_captures;
+    if (replays) *replays = c->g_replays;
+    return c->use_graph ? 1 : 0;
 }
 
 int lass_separate_components(lass_ctx* c, const float* const* mag, const float* cos_mask, const float* sin_mask,

@@ -411,6 +411,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
 #ifdef LASS_CONV_DIAG
             const long long t3 = clock64();
 #endif
+#ifdef LASS_CONV_DIAG
+            if (EXPF & 48) {  // sensitivity probe: 16 (bit 4) / 32 (bit 5) extra dependent-free VALU instructions in the prep phase
+                float dv0 = (float)tid, dv1 = dv0 + 1.f, dv2 = dv0 + 2.f, dv3 = dv0 + 3.f;
+                const int nrep = ((EXPF & 16) ? 4 : 0) + ((EXPF & 32) ? 8 : 0);
+                for (int q = 0; q < nrep; ++q)
+                    asm volatile("v_add_f32 %0, %0, %0\n\tv_add_f32 %1, %1, %1\n\tv_add_f32 %2, %2, %2\n\tv_add_f32 %3, %3, %3"
+                                 : "+v"(dv0), "+v"(dv1), "+v"(dv2), "+v"(dv3));
+                if (dv0 + dv1 + dv2 + dv3 == 1.2345f) lraw[0] = dv0;
+            }
+#endif
             // input transform V = B^T d B: one (channel, tile) item per thread and pass
             if (!(EXPF & 2))
 #pragma unroll
@@ -679,7 +689,7 @@ hipError_t launch_wino_v(const ConvArgs& p0, hipStream_t stream) {
     static const int exp_flags = [] { const char* e = getenv("LASS_EXP"); return e ? atoi(e) : 0; }();
     p.exp = exp_flags;
 #endif
-    const bool wide = p.N % 64 == 0;
+    const bool wide = p.N % 64 == 0;  // 32-cout blocks on the >= 64-cout layers: measured 10 % slower (V work doubles)
     if (p.W < 32) {  // 16- / 8-bin layers: 64-cout blocks of 8 x 16 or 16 x 8 output pixels
         if constexpr ((FLAGS & (F_MASK | F_PRECONV | F_RESPRE)) != 0) {
             return hipErrorInvalidValue;

@@ -319,6 +319,13 @@ class Engine:
         _lib.check(self.ctx, rc, "lass_mix_at_snr")
         return mixture
 
+    def graph_stats(self):
+        """(enabled, captures, replays) of the hipGraph replay of lass_separate."""
+        from ctypes import c_long
+        cap, rep = c_long(), c_long()
+        on = self.lib.lass_graph_stats(self.ctx, byref(cap), byref(rep))
+        return bool(on), cap.value, rep.value
+
     # ---- instrumentation -------------------------------------------------------------------------------------
     def set_profiling(self, on: bool):
         self.lib.lass_set_profiling(self.ctx, 1 if on else 0)

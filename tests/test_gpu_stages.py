@@ -175,3 +175,47 @@ def test_separate_rejects_bad_out_and_overlong_clips(model):
     with pytest.raises(LassError):
         eng.workspace_bytes(1, 32736 * 160)
     assert eng.workspace_bytes(1, 32736 * 160 - 1) > 0
+
+
+def test_graph_replay_equals_eager(synthetic_sd, monkeypatch):
+    """lass_separate captures its launches into a hipGraph when the same (pointers, shape) call repeats and replays it
+    afterwards: outputs must be bit-identical to the eager path, also after the INPUT CONTENT behind the same pointers
+    changes, and fresh buffers must fall back to eager without a re-capture per call."""
+    from lass_amd.resunet import ResUNet30
+
+    def make():
+        m = ResUNet30(1, 1, 512)
+        m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synthetic_sd.items()})
+        return m.to(DEV).eval()
+
+    B, L = 2, 24000
+    _, mix = synthetic.make_mixtures(2 * B, L)
+    cond = torch.from_numpy(synthetic.make_condition(B)).to(DEV)
+    x = torch.from_numpy(mix[:B]).to(DEV)
+    eng = make().engine
+    out = torch.empty_like(x)
+    outs = []
+    for i in range(4):
+        eng.separate(x, cond, out)
+        outs.append(out.clone())
+    on, caps, reps = eng.graph_stats()
+    assert on and caps == 1 and reps == 2, (on, caps, reps)   # eager, capture, replay, replay
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    x.copy_(torch.from_numpy(mix[B:]).to(DEV))                # same pointers, new audio: the replay must see it
+    eng.separate(x, cond, out)
+    replay_new = out.clone()
+    assert eng.graph_stats()[2] == 3 and not torch.equal(replay_new, outs[0])
+    monkeypatch.setenv("LASS_GRAPH", "0")
+    eng0 = make().engine
+    assert eng0.graph_stats()[0] is False
+    ref_new = eng0.separate(x, cond)
+    assert torch.equal(ref_new, replay_new)
+    ref_old = eng0.separate(torch.from_numpy(mix[:B]).to(DEV), cond)
+    assert torch.equal(ref_old, outs[0])
+    monkeypatch.delenv("LASS_GRAPH")
+    # fresh output buffers every call (what the evaluator does): no capture churn
+    caps_before = eng.graph_stats()[1]
+    for _ in range(3):
+        y = eng.separate(torch.from_numpy(mix[:B]).to(DEV).clone(), cond)
+    assert torch.equal(y, outs[0]) and eng.graph_stats()[1] <= caps_before + 1
