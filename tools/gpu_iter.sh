@@ -1,4 +1,4 @@
-# kernel iteration loop on the GPU box: conv parity tests, per-layer timing, short bench.  usage: bash tools/r2_kern.sh TAG [extra bench args]
+# kernel iteration loop on the GPU box: conv parity tests, per-layer timing, short bench.  usage: bash tools/gpu_iter.sh TAG [extra bench args]
 TAG=${1:-k}
 O=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $O
