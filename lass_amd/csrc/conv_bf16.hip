@@ -53,6 +53,9 @@ struct Phase16 {
     unsigned okbits;
     unsigned dvo[DMA ? NPC : 1];  // DMA: byte offset of this lane's unit in piece wave + 4*i (0xC0000000 = zero fill)
     // DMA kernels stage the weight slab by LDS-DMA too: rows (tap, octet) of NT couts x 16 B; a 1-KiB piece is RPP rows
+    // (bf16 mode only: with split operands the doubled image + slab, double-buffered, would leave one workgroup per CU -
+    // measured 8 % slower - so bf16x3 keeps the register-staged single weight region)
+    static constexpr bool WDMA = DMA && SPLIT == 1;
     static constexpr int RPP = 64 / NT;            // 1 (64-cout tiles) or 2 (32-cout tiles)
     static constexpr int NWPIECE = W1_U4 / 64;     // pieces per plane (hi or lo): 18 / 9 (3x3), 2 / 1 (1x1)
     static_assert(W1_U4 % 64 == 0, "whole pieces");
@@ -61,7 +64,7 @@ struct Phase16 {
     float v[(PRE || DMA) ? 1 : 2][(PRE || DMA) ? 1 : NPP][(PRE || DMA) ? 1 : 8];  // prefetched f32 activations: [octet][pass][channel in octet]
     float x0v[PRE ? NPP : 1];        // PRE: x0 at this thread's pixels
     float pcw[PRE ? KB : 1], pcb[PRE ? KB : 1];  // PRE: pre_conv weight / bias of the prefetched chunk's channels
-    uint4 wv[DMA ? 1 : SPLIT][DMA ? 1 : NWLD];  // prefetched bf16 weights (hi, lo); DMA kernels: unused
+    uint4 wv[(DMA && SPLIT == 1) ? 1 : SPLIT][(DMA && SPLIT == 1) ? 1 : NWLD];  // prefetched bf16 weights (hi, lo); unused when the slab is DMA'd
     float psc[KB], psh[KB];
 
     __device__ __forceinline__ static int upos(int tid, int k) {
@@ -156,7 +159,7 @@ struct Phase16 {
             }
         }
 #pragma unroll
-        for (int i = 0; i < (DMA ? 0 : NWLD); ++i) {
+        for (int i = 0; i < (WDMA ? 0 : NWLD); ++i) {
             wv[0][i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(w_rs, (int)woff[i], (int)wb, 0));
             if (SPLIT == 2)
                 wv[1][i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wl_rs, (int)woff[i], (int)wb, 0));
@@ -196,7 +199,7 @@ struct Phase16 {
                 if (SPLIT == 2) *reinterpret_cast<bf16x8*>(lds + IN1_U4 + o * NPIX + u) = pl;
             }
 #pragma unroll
-        for (int i = 0; i < NWLD; ++i) {
+        for (int i = 0; i < (WDMA ? 0 : NWLD); ++i) {
             const int e0 = tid + i * NTHREADS;
             const int e = e0 < W1_U4 ? e0 : W1_U4 - 1;
             wl[e] = wv[0][i];
@@ -283,8 +286,9 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
     using PA = Phase16<TAPS, NCO, NPX, PW, PRO, SPLIT, PRE, INBF>;
     constexpr bool IN2BF = (FLAGS & F_IN2BF16) != 0;  // phase B reads the blocked bf16 raw copy by LDS-DMA
     using PB = Phase16<1, NCO, NPX, PW, false, SPLIT, false, IN2BF>;
-    constexpr int PA_LDS = INBF ? 2 * PA::IN_U4 + 2 * PA::W_U4 : PA::LDS_U4;  // INBF: image and weights double-buffered
-    constexpr int PB_LDS = IN2BF ? 2 * PB::IN_U4 + 2 * PB::W_U4 : PB::LDS_U4;
+    // DMA-fed phases: image double-buffered; the weight slab too when it is DMA'd (bf16), else one register-staged region
+    constexpr int PA_LDS = INBF ? 2 * PA::IN_U4 + (PA::WDMA ? 2 : 1) * PA::W_U4 : PA::LDS_U4;
+    constexpr int PB_LDS = IN2BF ? 2 * PB::IN_U4 + (PB::WDMA ? 2 : 1) * PB::W_U4 : PB::LDS_U4;
     constexpr int LDS_U4 = HASB ? MaxU<PA_LDS, PB_LDS>::v : PA_LDS;
     constexpr int PH = PA::PH, WROWS = PA::WROWS, PHT = PA::PHT, NT = PA::NT;
     constexpr bool MASK = (FLAGS & F_MASK) != 0;
@@ -382,6 +386,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
         const v4i32 al_rs = SPLIT == 2
                                 ? make_rsrc_words(reinterpret_cast<const char*>(p.in_bf16_lo) + (size_t)b * plane, (unsigned)plane)
                                 : a_rs;
+        if constexpr (PA::WDMA) {
         const unsigned wbytes = (unsigned)(((long)(p.Cin / KB) * TAPS * 2 * p.Nw - n0) * 16);
         const v4i32 wd_rs = make_rsrc_words(wa, wbytes);
         const v4i32 wdl_rs = SPLIT == 2 ? make_rsrc_words(wa_lo, wbytes) : wd_rs;
@@ -403,6 +408,35 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
                               wl0 + (unsigned)((cur ^ 1) * PA::W_U4 * 16), wave);
             }
             PA::compute(lds4 + cur * PA::IN_U4, lds4 + 2 * PA::IN_U4 + cur * PA::W_U4, acc, lane, wave);
+        }
+        } else {
+            // split operands: image of chunk ch+1 by LDS-DMA into the other buffer while chunk ch is contracted; weights
+            // through registers into the single weight region between the two barriers
+            uint4* wl_d = lds4 + 2 * PA::IN_U4;
+            const unsigned img0 = (unsigned)(size_t)(__attribute__((address_space(3))) uint4*)lds4;
+            const unsigned img1 = img0 + (unsigned)(PA::IN_U4 * 16);
+            pa.init_dma(lane, wave, y0, x0, p.H, p.W);
+            pa.issue_dma(a_rs, al_rs, 0u, img0, wave);
+            loadA(0);
+            __syncthreads();  // epilogue tables visible
+            pa.store(lds4, wl_d, tid);
+            wait_vmcnt<0>();
+            __syncthreads();
+            init_acc();
+            for (int ch = 0; ch < nA; ++ch) {
+                const bool more = ch + 1 < nA;
+                if (more) {
+                    pa.issue_dma(a_rs, al_rs, (unsigned)((ch + 1) * 2 * HW) * 16u, (ch & 1) ? img0 : img1, wave);
+                    loadA(ch + 1);
+                }
+                PA::compute(lds4 + ((ch & 1) ? PA::IN_U4 : 0), wl_d, acc, lane, wave);
+                __syncthreads();
+                if (more) {
+                    pa.store(lds4, wl_d, tid);
+                    wait_vmcnt<0>();
+                }
+                __syncthreads();
+            }
         }
     } else {
         pa.init(tid, y0, x0, p.H, p.W);
@@ -449,6 +483,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
         // same schedule as the INBF main phase: image and weights by LDS-DMA into alternating buffers
         const long plane2 = (long)(p.Cin2 / 8) * HW * 16;
         const v4i32 r_rs = make_rsrc_words(reinterpret_cast<const char*>(p.in2_bf16) + (size_t)b * plane2, (unsigned)plane2);
+        if constexpr (PB::WDMA) {
         const unsigned wbytes2 = (unsigned)(((long)(p.Cin2 / KB) * 2 * p.Nw - n0) * 16);
         const v4i32 wd_rs = make_rsrc_words(wb2, wbytes2);
         const v4i32 wdl_rs = SPLIT == 2 ? make_rsrc_words(wb2_lo, wbytes2) : wd_rs;
@@ -469,6 +504,32 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
                               wl0 + (unsigned)((cur ^ 1) * PB::W_U4 * 16), wave);
             }
             PB::compute(lds4 + cur * PB::IN_U4, lds4 + 2 * PB::IN_U4 + cur * PB::W_U4, acc, lane, wave);
+        }
+        } else {
+            uint4* wl_b = lds4 + 2 * PB::IN_U4;
+            const unsigned img0 = (unsigned)(size_t)(__attribute__((address_space(3))) uint4*)lds4;
+            const unsigned img1 = img0 + (unsigned)(PB::IN_U4 * 16);
+            pb.init_dma(lane, wave, y0, x0, p.H, p.W);
+            __syncthreads();  // phase A has finished with the LDS
+            pb.issue_dma(r_rs, r_rs, 0u, img0, wave);
+            loadB(0);
+            pb.store(lds4, wl_b, tid);
+            wait_vmcnt<0>();
+            __syncthreads();
+            for (int ch = 0; ch < nB; ++ch) {
+                const bool more = ch + 1 < nB;
+                if (more) {
+                    pb.issue_dma(r_rs, r_rs, (unsigned)((ch + 1) * 2 * HW) * 16u, (ch & 1) ? img0 : img1, wave);
+                    loadB(ch + 1);
+                }
+                PB::compute(lds4 + ((ch & 1) ? PB::IN_U4 : 0), wl_b, acc, lane, wave);
+                __syncthreads();
+                if (more) {
+                    pb.store(lds4, wl_b, tid);
+                    wait_vmcnt<0>();
+                }
+                __syncthreads();
+            }
         }
     } else if (HASB) {
         uint4* wl_b = lds4 + PB::IN_U4;
