@@ -267,6 +267,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
     const unsigned slab_pitch = (unsigned)(p.Nw / 32) * 16384u;  // bytes between the slabs of consecutive chunks
     const unsigned slab_n0 = (unsigned)(n0 / 32) * 16384u;
 
+#ifdef LASS_CONV_DIAG
+    const long long k_main0 = clock64();
+#endif
     // ---- main phase: 3x3 over p.in ------------------------------------------------------------------------------
     // Per chunk:  barrier | raw(ch) regs->LDS | issue U(ch) LDS-DMA | issue raw(ch+2) loads | barrier |
     //             transform raw->V | wait U(ch) (counted vmcnt: the raw(ch+2) loads stay in flight) | barrier |
@@ -478,6 +481,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
             chunk(ch + 1, std::integral_constant<int, 1>{});
         }
     }
+#ifdef LASS_CONV_DIAG
+    const long long k_sc0 = clock64();
+#endif
     // ---- shortcut phase: 1x1 over p.in2, in the transform domain (xi in {5,6,9,10}) -------------------------------
     // Chunks of 32 channels: a thread owns one tile position and channels cb + i*CSTEP; it loads the 2x2 patch centres
     // straight from global (two aligned 8-byte loads per item, issued one chunk ahead: they land during the MFMAs) and
@@ -542,10 +548,35 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
         }
     }
 
+#ifdef LASS_CONV_DIAG
+    const long long k_epi0 = clock64();
+#endif
     // ---- output transform Y = A^T M A and epilogue -----------------------------------------------------------------
     const int wty = (wwt * 16 + l15) / PWT, wtx = (wwt * 16 + l15) % PWT;  // this lane's tile within the block
     const int oy = y0 + 2 * wty, ox = x0 + 2 * wtx;
     float ml[3][2][2] = {};  // MASK: this lane's partial after_conv logits of its 2x2 pixels (8 of the 32 channels)
+    // Residual values of all 8 channels first, in one batch of loads: inside the store loop below the compiler cannot
+    // move a load of p.res above the preceding store to p.out (they may alias for all it knows), which serialised eight
+    // global-load round trips per workgroup (16 000 cycles of a 44 000-cycle encoder_block1.conv2 block).
+    float2 rres[(RES && !RESPRE) ? 2 : 1][(RES && !RESPRE) ? 4 : 1][2];
+    if (RES) {
+        const size_t rpix = (size_t)min(oy, p.H - 1) * p.W + ox;
+        const int rrow = oy + 1 < p.H ? p.W : 0;
+        if (RESPRE) {  // one x0 patch serves every channel
+            const float* rp = p.res + (size_t)b * p.res_bs + rpix;
+            rres[0][0][0] = *reinterpret_cast<const float2*>(rp);
+            rres[0][0][1] = *reinterpret_cast<const float2*>(rp + rrow);
+        } else {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float* rp = p.res + (size_t)b * p.res_bs + (size_t)(n0 + wco * 32 + t * 16 + kq * 4 + r) * HW + rpix;
+                    rres[(RES && !RESPRE) ? t : 0][(RES && !RESPRE) ? r : 0][0] = *reinterpret_cast<const float2*>(rp);
+                    rres[(RES && !RESPRE) ? t : 0][(RES && !RESPRE) ? r : 0][1] = *reinterpret_cast<const float2*>(rp + rrow);
+                }
+        }
+    }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
 #pragma unroll
@@ -570,10 +601,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
                 y[0][0] += bb; y[0][1] += bb; y[1][0] += bb; y[1][1] += bb;
             }
             if (RES) {
-                const float* rp = p.res + (size_t)b * p.res_bs + (RESPRE ? 0 : (size_t)n * HW) +
-                                  (size_t)min(oy, p.H - 1) * p.W + ox;
-                float2 r0 = *reinterpret_cast<const float2*>(rp);
-                float2 r1 = *reinterpret_cast<const float2*>(rp + (oy + 1 < p.H ? p.W : 0));
+                float2 r0 = rres[RESPRE ? 0 : t][RESPRE ? 0 : r][0], r1 = rres[RESPRE ? 0 : t][RESPRE ? 0 : r][1];
                 if (RESPRE) {  // residual = pre_conv(x0): resunet.py:555,165
                     const float pw = lds_pw[nl], pb = lds_pb[nl];
                     r0.x = r0.x * pw + pb; r0.y = r0.y * pw + pb; r1.x = r1.x * pw + pb; r1.y = r1.y * pw + pb;
@@ -635,10 +663,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
     }
 #ifdef LASS_CONV_DIAG
     if (p.dbg && tid == 0) {
-        long long* d = p.dbg + 8 * ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+        long long* d = p.dbg + 12 * ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
         for (int i = 0; i < 6; ++i) d[i] = dg[i];
-        d[6] = clock64() - k_c0;
+        const long long k_end = clock64();
+        d[6] = k_end - k_c0;
         d[7] = wall_clock64() - k_r0;
+        d[8] = k_main0 - k_c0;   // kernel prologue (tables, accumulator init)
+        d[9] = k_sc0 - k_main0;  // main phase incl. its own start-up (first loads)
+        d[10] = k_epi0 - k_sc0;  // shortcut phase
+        d[11] = k_end - k_epi0;  // output transform + epilogue
     }
 #endif
 }
@@ -711,7 +744,7 @@ hipError_t launch_wino_v(const ConvArgs& p0, hipStream_t stream) {
     const size_t nblk = (size_t)grid.x * grid.y * grid.z;
     if (nblk > dcap) {
         if (dbuf) (void)hipFree(dbuf);
-        (void)hipMalloc((void**)&dbuf, nblk * 64);
+        (void)hipMalloc((void**)&dbuf, nblk * 96);
         dcap = nblk;
     }
     p.dbg = dbuf;
@@ -727,19 +760,20 @@ hipError_t launch_wino_v(const ConvArgs& p0, hipStream_t stream) {
     }
 #ifdef LASS_CONV_DIAG
     {
-        std::vector<long long> h(nblk * 8);
+        std::vector<long long> h(nblk * 12);
         (void)hipDeviceSynchronize();
-        (void)hipMemcpy(h.data(), dbuf, nblk * 64, hipMemcpyDeviceToHost);
-        double s[8] = {0};
+        (void)hipMemcpy(h.data(), dbuf, nblk * 96, hipMemcpyDeviceToHost);
+        double s[12] = {0};
         for (size_t i = 0; i < nblk; ++i)
-            for (int k = 0; k < 8; ++k) s[k] += (double)h[i * 8 + k];
+            for (int k = 0; k < 12; ++k) s[k] += (double)h[i * 12 + k];
         const double nch = p.Cin / 8.0;
         for (double& v : s) v /= (double)nblk;
         fprintf(stderr,
                 "[wino-diag] Cin=%d N=%d %dx%d blocks=%zu | per chunk: barA %.0f  store+issue %.0f  barB %.0f  transform %.0f  "
-                "waitU+barC %.0f  mfma %.0f | block total %.0f cycles, clock %.3f GHz\n",
-                p.Cin, p.N, p.H, p.W, nblk, s[0] / nch, s[1] / nch, s[2] / nch, s[3] / nch, s[4] / nch, s[5] / nch, s[6],
-                s[6] / s[7] * 0.1);
+                "waitU+barC %.0f  mfma %.0f | block total %.0f cycles = prologue %.0f + main %.0f + shortcut %.0f + epilogue %.0f, "
+                "clock %.3f GHz\n",
+                p.Cin, p.N, p.H, p.W, nblk, s[0] / nch, s[1] / nch, s[2] / nch, s[3] / nch, s[4] / nch, s[5] / nch, s[6], s[8],
+                s[9], s[10], s[11], s[6] / s[7] * 0.1);
     }
 #endif
     return hipGetLastError();
