@@ -222,3 +222,61 @@ def test_multistft_limits_and_modes(ms_model):
     assert eng.workspace_bytes(1, 8100 * 160) > 0
     with pytest.raises(NotImplementedError):
         ms_model.set_compute_dtype("bf16")
+
+
+@pytest.mark.gpu
+def test_multistft_c_abi_error_paths(ms_model):
+    """lass_create_multistft / lass_separate_components / lass_stft_components / lass_istft_nfft misuse: negative code +
+    message, never a crash or a silent fallback."""
+    from ctypes import POINTER, byref, c_int, c_void_p
+    from lass_amd import _lib
+    lib = _lib.load()
+    h = c_void_p()
+    wins = (c_int * 3)(256, 512, 2048)
+    assert lib.lass_create_multistft(byref(h), 0, 1024, 3, wins, 512) < 0          # n_fft must be 2048
+    assert b"2048" in lib.lass_last_error(None)
+    assert lib.lass_create_multistft(byref(h), 0, 2048, 3, wins, 1024) < 0         # mask window not analysed
+    assert lib.lass_create_multistft(byref(h), 0, 2048, 3, (c_int * 3)(256, 256, 512), 512) < 0   # duplicate window
+    assert lib.lass_create_multistft(byref(h), 0, 2048, 2, (c_int * 2)(300, 512), 512) < 0        # not a power of two
+    assert lib.lass_create_multistft(byref(h), 0, 2048, 5, wins, 512) < 0
+    eng = ms_model.engine
+    B, L = 1, 8000
+    T = arch.frames_for(L)
+    mags = [torch.rand(B, T, 1025, device=DEV) for _ in WINS]
+    cos = torch.rand(B, T, 1025, device=DEV)
+    cond = torch.zeros(B, 512, device=DEV)
+    with pytest.raises(_lib.LassError):
+        eng.separate_components(mags[:2], cos, cos, cond, L)                       # a branch is missing
+    with pytest.raises(_lib.LassError):
+        eng.separate_components(mags, cos[:, :-1].contiguous(), cos, cond, L)      # frame count mismatch
+    with pytest.raises(_lib.LassError):
+        eng.separate_components(mags, cos, cos, cond, L + 160)                     # target length inconsistent with T
+    out = eng.separate_components(mags, cos, cos, cond, L)
+    assert out.shape == (B, L) and torch.isfinite(out).all()
+    x = torch.zeros(1, 4000, device=DEV)
+    with pytest.raises(_lib.LassError):
+        eng.stft_components(x, 2048, [300])
+    with pytest.raises(_lib.LassError):
+        eng.stft_components(x, 512, [256])                                          # n_fft 1024 or 2048 only
+    with pytest.raises(_lib.LassError):
+        eng.stft_components(torch.zeros(1, 1000, device=DEV), 2048, [512])         # shorter than the reflect padding
+    with pytest.raises(_lib.LassError):
+        eng.istft_nfft(torch.zeros(1, 10, 1025, device=DEV), torch.zeros(1, 10, 1025, device=DEV), 100000, 2048, 512)
+
+
+@pytest.mark.gpu
+def test_multistft_chunk_inference_stitches_like_whole_clip(ms_model):
+    """chunk_inference (resunet.py:655-714 control flow) on the multi-STFT model: windows are separated 4 per launch and
+    stitched; in the interior of each window's kept region the result must track the whole-clip forward (the network's
+    receptive field is shorter than the 1 s of context on each side only approximately: loose bound)."""
+    L = 400000
+    segs = [synthetic.make_mixtures(1, 160000, first=30 + i)[1][0] for i in range(3)]
+    mix = np.concatenate(segs)[None, None, :L].astype(np.float32)
+    cond = synthetic.make_condition(1)
+    inp = {"mixture": torch.from_numpy(mix).to(DEV), "condition": torch.from_numpy(cond).to(DEV)}
+    out = ms_model.chunk_inference(inp)
+    assert out.shape == (1, L) and out.dtype == np.float64 and np.isfinite(out).all()
+    whole = ms_model(inp)["waveform"][0].cpu().numpy().astype(np.float64)
+    mid = slice(32000 + 16000, 128000 - 16000)     # inside the first window's kept centre, away from its seams
+    err = np.sqrt(np.mean((out[:, mid] - whole[:, mid]) ** 2))
+    assert err < 0.1 * np.sqrt(np.mean(whole[:, mid] ** 2)), err
