@@ -254,6 +254,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_kernel_db(ConvArgs p) {
     constexpr int PH = PA::PH, WROWS = PA::WROWS, PHT = PA::PHT, NT = PA::NT;
     constexpr bool EPI = (FLAGS & F_EPIACT) != 0;
 
+    static_assert(LDS_MAIN % 4 == 0, "epilogue tables are read as float4");
     __shared__ __attribute__((aligned(16))) float lds[LDS_MAIN + (EPI ? 2 * NT : 0)];
     float* lds_es = lds + LDS_MAIN;  // epilogue scale / shift for this block's NT output channels
     float* lds_eh = lds_es + NT;
@@ -341,6 +342,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_kernel_sb(ConvArgs p) {
     constexpr bool MASK = (FLAGS & F_MASK) != 0;
     constexpr int NTAB = (EPI ? 2 * NT : 0) + (BIAS ? NT : 0) + (RESPRE ? 2 * NT : 0) + (MASK ? 100 : 0);
 
+    static_assert(LDS_ONE % 4 == 0, "epilogue tables are read as float4");
     __shared__ __attribute__((aligned(16))) float lds[LDS_ONE + NTAB];
     float* lds_mw = lds + LDS_ONE + NTAB - 100;  // MASK: after_conv weight [3][32] + bias [3]
     float* lds_es = lds + LDS_ONE;  // epilogue scale / shift for this block's NT output channels

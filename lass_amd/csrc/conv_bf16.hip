@@ -11,6 +11,9 @@
 //   weights [tap][cin-octet (2)][cout][8 x bf16]     lane (h, n): octet h, cout n
 // A chunk is 16 input channels = one MFMA K; per chunk a wave issues TAPS x NCO x NPX MFMAs.
 #include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
 #include "conv_common.h"
 #include "kernels.h"
 #include "wino_common.h"  // make_rsrc_words, lds_dma_16B, wait_vmcnt
@@ -347,6 +350,13 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
         }
     }
 
+#ifdef LASS_CONV_DIAG
+    const int EXPF = p.exp;  // timing experiments (LASS_EXP; wrong results): 1 no weight DMA, 2 no image DMA, 8 no MFMA
+    const long long dg_t0 = clock64();
+    long long dg_t1 = dg_t0, dg_t2 = dg_t0, dg_t3 = dg_t0;
+#else
+    constexpr int EXPF = 0;
+#endif
     PA pa;
     PB pb;
     const auto rs = [](const void* ptr, long bytes) {
@@ -398,16 +408,19 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
         pa.issue_wdma(wd_rs, wdl_rs, 0u, p.Nw, wl0, wave);
         __syncthreads();  // epilogue tables visible
         init_acc();
+#ifdef LASS_CONV_DIAG
+        dg_t1 = clock64();
+#endif
         for (int ch = 0; ch < nA; ++ch) {
             const int cur = ch & 1;
             wait_vmcnt<0>();   // this wave's pieces of chunk ch have landed
             __syncthreads();   // ... everyone's have, and everyone has finished contracting chunk ch-1
             if (ch + 1 < nA) {
-                pa.issue_dma(a_rs, al_rs, (unsigned)((ch + 1) * 2 * HW) * 16u, img0 + (unsigned)((cur ^ 1) * PA::IN_U4 * 16), wave);
-                pa.issue_wdma(wd_rs, wdl_rs, (unsigned)((ch + 1) * TAPS * 2 * p.Nw) * 16u, p.Nw,
+                if (!(EXPF & 2)) pa.issue_dma(a_rs, al_rs, (unsigned)((ch + 1) * 2 * HW) * 16u, img0 + (unsigned)((cur ^ 1) * PA::IN_U4 * 16), wave);
+                if (!(EXPF & 1)) pa.issue_wdma(wd_rs, wdl_rs, (unsigned)((ch + 1) * TAPS * 2 * p.Nw) * 16u, p.Nw,
                               wl0 + (unsigned)((cur ^ 1) * PA::W_U4 * 16), wave);
             }
-            PA::compute(lds4 + cur * PA::IN_U4, lds4 + 2 * PA::IN_U4 + cur * PA::W_U4, acc, lane, wave);
+            if (!(EXPF & 8)) PA::compute(lds4 + cur * PA::IN_U4, lds4 + 2 * PA::IN_U4 + cur * PA::W_U4, acc, lane, wave);
         }
         } else {
             // split operands: image of chunk ch+1 by LDS-DMA into the other buffer while chunk ch is contracted; weights
@@ -454,6 +467,9 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
             __syncthreads();
         }
     }
+#ifdef LASS_CONV_DIAG
+    dg_t2 = clock64();
+#endif
     float rtmp[RES_PF ? NPX : 1][16];
     if (HASB) {
         if (!IN2BF) pb.init(tid, y0, x0, p.H, p.W);
@@ -545,11 +561,21 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
         }
         PB::compute(lds4, wl_b, acc, lane, wave);
     }
+#ifdef LASS_CONV_DIAG
+    dg_t3 = clock64();
+#endif
     if (FLAGS & F_TCONV)
         tconv_store<NCO, NPX, PW>(p, acc, b, n0, y0, x0, lane, wave, lds_tact);
     else
         store_tile<NCO, NPX, PW, FLAGS, RES_PF>(p, acc, rtmp, lds_es, lds_eh, b, n0, y0, x0, lane, wave,
                                                  MASK ? lds_mw : nullptr, OUTBF ? lds_act : nullptr);
+#ifdef LASS_CONV_DIAG
+    if (p.dbg && tid == 0) {
+        long long* d = p.dbg + 4 * ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+        const long long te = clock64();
+        d[0] = dg_t1 - dg_t0; d[1] = dg_t2 - dg_t1; d[2] = dg_t3 - dg_t2; d[3] = te - dg_t3;
+    }
+#endif
 }
 
 // dst[chunk][tap][octet][Cout][8] (bf16, RNE) = src[co][ci = chunk*16 + octet*8 + j][tap]   (taps = 9 or 1)
@@ -572,7 +598,35 @@ __global__ __launch_bounds__(256) void weights_bf16_kernel(const float* __restri
 }
 
 template <int TAPS, int NCO, int NPX, int PW, int FLAGS>
-hipError_t launch_bf16_one(const ConvArgs& p, hipStream_t stream) {
+hipError_t launch_bf16_one(const ConvArgs& p0, hipStream_t stream) {
+    ConvArgs p = p0;
+#ifdef LASS_CONV_DIAG
+    static const int exp_flags = [] { const char* e = getenv("LASS_EXP"); return e ? atoi(e) : 0; }();
+    p.exp = exp_flags;
+    static long long* dbuf = nullptr;
+    static size_t dcap = 0;
+    constexpr int PHTd = 4 * NPX * (32 / PW);
+    const size_t nblk = (size_t)(p.W / PW) * ((p.H + PHTd - 1) / PHTd) * (p.N / (32 * NCO)) * p.B;
+    if (nblk > dcap) {
+        if (dbuf) (void)hipFree(dbuf);
+        (void)hipMalloc((void**)&dbuf, nblk * 32);
+        dcap = nblk;
+    }
+    p.dbg = dbuf;
+    struct Report {
+        const ConvArgs& p; size_t nblk; long long* dbuf;
+        ~Report() {
+            std::vector<long long> h(nblk * 4);
+            (void)hipDeviceSynchronize();
+            (void)hipMemcpy(h.data(), dbuf, nblk * 32, hipMemcpyDeviceToHost);
+            double s[4] = {0, 0, 0, 0};
+            for (size_t i = 0; i < nblk; ++i) for (int k = 0; k < 4; ++k) s[k] += (double)h[i * 4 + k];
+            fprintf(stderr, "[bf16-diag] taps=%d NCO=%d NPX=%d flags=%d Cin=%d Cin2=%d N=%d %dx%d blocks=%zu | cycles per block: prologue %.0f  "
+                    "main %.0f (%.0f per chunk)  shortcut %.0f  epilogue %.0f\n", TAPS, NCO, NPX, FLAGS, p.Cin, p.Cin2, p.N, p.H, p.W, nblk,
+                    s[0] / nblk, s[1] / nblk, s[1] / nblk / (p.Cin / 16.0), s[2] / nblk, s[3] / nblk);
+        }
+    } report{p, nblk, dbuf};
+#endif
     constexpr int PHT = 4 * NPX * (32 / PW);
     dim3 grid((p.W / PW) * ((p.H + PHT - 1) / PHT), p.N / (32 * NCO), p.B);
     if constexpr ((FLAGS & F_NOSPLIT) != 0) {

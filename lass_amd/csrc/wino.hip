@@ -622,9 +622,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
                 }
                 continue;
             }
-            float* dst = p.out + (size_t)b * p.out_bs + pix;
-            if (oy < p.H) *reinterpret_cast<float2*>(dst) = make_float2(y[0][0], y[0][1]);
-            if (oy + 1 < p.H) *reinterpret_cast<float2*>(dst + p.W) = make_float2(y[1][0], y[1][1]);
+            // 16-byte stores: the lane pair (l, l^1) holds two horizontally adjacent 2x2 tiles; the even lane takes the upper
+            // row of both (4 consecutive floats), the odd lane the lower row - 8 dwordx4 instead of 16 dwordx2 stores per
+            // lane (the store tail of a workgroup is issue-bound).  H is even, so both rows of a tile are in range together.
+            {
+                const bool odd = (lane & 1) != 0;
+                const float sx = odd ? y[0][0] : y[1][0], sy = odd ? y[0][1] : y[1][1];  // the row the partner stores
+                const float rx = __shfl_xor(sx, 1, 64), ry = __shfl_xor(sy, 1, 64);
+                float* dst = p.out + (size_t)b * p.out_bs + pix;
+                const float4 v = odd ? make_float4(rx, ry, y[1][0], y[1][1]) : make_float4(y[0][0], y[0][1], rx, ry);
+                if (oy < p.H) *reinterpret_cast<float4*>(odd ? dst + p.W - 2 : dst) = v;
+            }
             if (p.pool_out) {
                 const int Wo = p.W / 2;
                 const size_t pool_bs = p.pool_bs ? (size_t)p.pool_bs : (size_t)p.N * (p.H / p.pool_h) * Wo;
