@@ -101,9 +101,9 @@ int lass_workspace_bytes(const lass_ctx* ctx, int B, int L, size_t* bytes);
 int lass_separate(lass_ctx* ctx, const float* mixture, const float* condition, float* out, int B, int L,
                   void* workspace, size_t workspace_bytes, void* stream);
 
-/* Graph replay.  A lass_separate call whose pointers, shape and stream-independent state equal the previous call's is
- * captured into a hipGraph once and replayed on the caller's stream from then on (one graph per context; a different
- * combination is captured anew after it has been seen twice in a row).  Nothing else about the call changes; profiled
+/* Graph replay.  The third consecutive lass_separate call with the same pointers and shape is captured into a hipGraph
+ * and replayed on the caller's stream from then on (one graph per context; a different combination is captured anew
+ * after it, too, has been seen three times in a row).  Nothing else about the call changes; profiled
  * contexts and LASS_GRAPH=0 stay eager.  Returns 1 if replay is enabled, 0 if not; counters are optional outputs. */
 int lass_graph_stats(const lass_ctx* ctx, long* captures, long* replays);
 

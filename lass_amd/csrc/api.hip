@@ -119,6 +119,7 @@ struct lass_ctx {
         }
     };
     GraphKey g_key, g_seen;        // key of the instantiated graph / of the previous call
+    int g_seen_count = 0;          // consecutive eager calls with g_seen
     hipGraphExec_t g_exec = nullptr;
     hipStream_t g_stream = nullptr;
     unsigned long gen = 0;         // bumped by lass_finalize: a graph holds weight pointers
@@ -1271,7 +1272,7 @@ int lass_separate(lass_ctx* c, const float* mixture, const float* condition, flo
                   size_t workspace_bytes, void* stream) {
     if (!c) return LASS_ERR_ARG;
     if (!mixture) return fail(c, LASS_ERR_ARG, "lass_separate: null pointer");
-    // Graph replay: a call whose pointers and shape equal the PREVIOUS call's is captured once (on an internal stream; the
+    // Graph replay: a call whose pointers and shape equal those of the two PREVIOUS calls is captured once (on an internal stream; the
     // caller's may be the legacy default stream, which cannot be captured) and replayed from then on.  Callers that hand
     // over fresh buffers every time (the evaluator loop) simply stay on the eager path; so does a profiled context.
     lass_ctx::GraphKey key;
@@ -1283,7 +1284,7 @@ int lass_separate(lass_ctx* c, const float* mixture, const float* condition, flo
             ++c->g_replays;
             return 0;
         }
-        if (key == c->g_seen) {  // second identical call in a row: worth a capture
+        if (key == c->g_seen && c->g_seen_count >= 2) {  // third identical call in a row: worth a capture
             HIP_TRY(c, hipSetDevice(c->device));
             if (!c->g_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->g_stream, hipStreamNonBlocking));
             if (c->g_exec) { (void)hipGraphExecDestroy(c->g_exec); c->g_exec = nullptr; }
@@ -1310,6 +1311,7 @@ int lass_separate(lass_ctx* c, const float* mixture, const float* condition, flo
             }
         }
     }
+    c->g_seen_count = (key == c->g_seen) ? c->g_seen_count + 1 : 1;
     c->g_seen = key;
     return separate_impl(c, mixture, nullptr, condition, out, B, L, workspace, workspace_bytes, stream, "lass_separate");
 }

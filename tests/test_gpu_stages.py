@@ -195,11 +195,11 @@ def test_graph_replay_equals_eager(synthetic_sd, monkeypatch):
     eng = make().engine
     out = torch.empty_like(x)
     outs = []
-    for i in range(4):
+    for i in range(5):
         eng.separate(x, cond, out)
         outs.append(out.clone())
     on, caps, reps = eng.graph_stats()
-    assert on and caps == 1 and reps == 2, (on, caps, reps)   # eager, capture, replay, replay
+    assert on and caps == 1 and reps == 2, (on, caps, reps)   # eager, eager, capture, replay, replay
     for o in outs[1:]:
         assert torch.equal(o, outs[0])
     x.copy_(torch.from_numpy(mix[B:]).to(DEV))                # same pointers, new audio: the replay must see it
