@@ -25,16 +25,18 @@ def mix(source: np.ndarray, noise: np.ndarray, snr: int):
     return source, mixture
 
 
-def evaluate(sd, clips, conditions):
+def evaluate(sd, clips, conditions, forward=None):
     """clips: iterable of (source, noise, snr); conditions: (N,512).  Returns
-    (mean_sisdr, mean_sdri, mean_sdr), per-clip array (N,3) of [sdr, sdri, sisdr]  (dcase_evaluator.py:91-122)."""
+    (mean_sisdr, mean_sdri, mean_sdr), per-clip array (N,3) of [sdr, sdri, sisdr]  (dcase_evaluator.py:91-122).
+    `forward(sd, input_dict) -> {'waveform': (1,1,L)}` defaults to the ResUNet30 oracle (pl_model.ss_model of :104)."""
+    forward = forward or resunet.forward
     rows = []
     for i, (source, noise, snr) in enumerate(clips):
         source, mixture = mix(source, noise, int(snr))
         sdr_no_sep = metrics.calculate_sdr(ref=source, est=mixture)
         inp = {"mixture": torch.Tensor(mixture)[None, None, :],
                "condition": torch.as_tensor(conditions[i:i + 1])}
-        sep = resunet.forward(sd, inp)["waveform"].squeeze(0).squeeze(0).numpy()
+        sep = forward(sd, inp)["waveform"].squeeze(0).squeeze(0).numpy()
         sdr = metrics.calculate_sdr(ref=source, est=sep)
         rows.append([sdr, sdr - sdr_no_sep, metrics.calculate_sisdr(ref=source, est=sep)])
     rows = np.asarray(rows, dtype=np.float64)

@@ -280,3 +280,24 @@ def test_multistft_chunk_inference_stitches_like_whole_clip(ms_model):
     mid = slice(32000 + 16000, 128000 - 16000)     # inside the first window's kept centre, away from its seams
     err = np.sqrt(np.mean((out[:, mid] - whole[:, mid]) ** 2))
     assert err < 0.1 * np.sqrt(np.mean(whole[:, mid] ** 2)), err
+
+
+@pytest.mark.gpu
+def test_dcase_evaluator_drives_the_multistft_model(tmp_path, ms_model, ms_sd):
+    """The evaluator interface (dcase_evaluator.py:49-122) with the multi-STFT separator as `pl_model.ss_model`: same
+    loop, same metrics, against the oracle evaluator running the multi-STFT oracle forward."""
+    import os
+    from lass_amd.audiosep import AudioSep, PrecomputedQueryEncoder
+    from lass_amd.evaluator import DCASEEvaluator
+    from oracle import evaluator as oev
+    n, L = 5, 24000
+    csv_path = synthetic.write_validation_set(str(tmp_path), n_clips=n, length=L)
+    qe = PrecomputedQueryEncoder()
+    ev = DCASEEvaluator(sampling_rate=16000, eval_indexes=csv_path, audio_dir=os.path.join(str(tmp_path), "lass_validation"),
+                        batch_size=2)
+    sisdr, sdri, sdr = ev(AudioSep(ss_model=ms_model, query_encoder=qe))
+    clips = [synthetic.make_clip(i, L) for i in range(n)]
+    conds = qe.get_query_embed("text", [f"synthetic tone cluster {i % 4}" for i in range(n)]).numpy()
+    (o_sisdr, o_sdri, o_sdr), rows = oev.evaluate(orr.to_torch(ms_sd), clips, conds, forward=oms.forward)
+    np.testing.assert_allclose(ev.last_rows, rows, atol=0.01)
+    assert abs(sdr - o_sdr) < 0.01 and abs(sdri - o_sdri) < 0.01 and abs(sisdr - o_sisdr) < 0.01
