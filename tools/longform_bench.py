@@ -4,9 +4,9 @@
   * ResUNet30 whole-clip forward;
   * the multi-STFT separator (lass_amd/resunet_with_multistft.py) whole-clip forward, B = 1 and B = 2.
 Prints one line per case: ms per clip, clips/s, x real time."""
-import sys, time
+import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lass_amd import arch, synthetic
 from lass_amd.resunet import ResUNet30
 from lass_amd.resunet_with_multistft import ResUNet30 as MultiSTFT
