@@ -310,10 +310,11 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.z;
-    const int n0 = blockIdx.y * NT;
+    int bx_, by_, b;
+    block_coords(p, bx_, by_, b);
+    const int n0 = by_ * NT;
     const int tiles_x = p.W / PW;
-    const int y0 = (blockIdx.x / tiles_x) * PHT, x0 = (blockIdx.x % tiles_x) * PW;
+    const int y0 = (bx_ / tiles_x) * PHT, x0 = (bx_ % tiles_x) * PW;
     const int HW = p.H * p.W;
     const int khalf = lane >> 5, j = lane & 31;
     const int ty = j / PW, tx = j % PW;
@@ -571,7 +572,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
                                                  MASK ? lds_mw : nullptr, OUTBF ? lds_act : nullptr);
 #ifdef LASS_CONV_DIAG
     if (p.dbg && tid == 0) {
-        long long* d = p.dbg + 4 * ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+        long long* d = p.dbg + 4 * (size_t)blockIdx.x;
         const long long te = clock64();
         d[0] = dg_t1 - dg_t0; d[1] = dg_t2 - dg_t1; d[2] = dg_t3 - dg_t2; d[3] = te - dg_t3;
     }
@@ -628,7 +629,11 @@ hipError_t launch_bf16_one(const ConvArgs& p0, hipStream_t stream) {
     } report{p, nblk, dbuf};
 #endif
     constexpr int PHT = 4 * NPX * (32 / PW);
-    dim3 grid((p.W / PW) * ((p.H + PHT - 1) / PHT), p.N / (32 * NCO), p.B);
+    p.gx = (p.W / PW) * ((p.H + PHT - 1) / PHT);
+    p.gy = p.N / (32 * NCO);
+    static const bool xcd = [] { const char* e = getenv("LASS_XCD_MAP"); return !e || atoi(e) != 0; }();
+    p.xcd_map = (xcd && p.gy > 1 && ((long)p.gx * p.B) % 8 == 0) ? 1 : 0;
+    dim3 grid((unsigned)((long)p.gx * p.gy * p.B));
     if constexpr ((FLAGS & F_NOSPLIT) != 0) {
         if (p.w_bf16_lo) return hipErrorInvalidValue;
         hipLaunchKernelGGL((conv_bf16_kernel<TAPS, NCO, NPX, PW, FLAGS, 1>), grid, dim3(NTHREADS), 0, stream, p);

@@ -82,6 +82,9 @@ struct ConvArgs {
     long pool_bs = 0;            // elements between clips of pool_out; 0 = dense (N * H/pool_h * W/2).  A launch that
                                  // produces a channel slice of a wider pooled tensor passes the wide tensor's stride.
     int pool_h = 2;              // vertical pool factor (1 or 2); horizontal is 2
+    // XCD-aware block order (wino.hip, conv_bf16.hip): launched as a 1-D grid of gx * gy * B workgroups; set by the launcher
+    int gx = 0, gy = 0;        // spatial tiles per clip, cout blocks
+    int xcd_map = 0;           // 1: the gy cout blocks of one (tile, clip) run on ONE XCD (they re-read the same input tile)
     long long* dbg = nullptr;  // diagnostic builds (-DLASS_CONV_DIAG) only: 8 int64 per block
     int exp = 0;  // diagnostic builds only: timing-experiment switches (env LASS_EXP, see wino.hip)
 };

@@ -217,10 +217,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // uniform to the compiler too
     const int wco = wave / WWT, wwt = wave % WWT;
-    const int b = blockIdx.z;
-    const int n0 = blockIdx.y * NT;
+    int bx_, by_, b;
+    block_coords(p, bx_, by_, b);
+    const int n0 = by_ * NT;
     const int tiles_x = p.W / OC;
-    const int y0 = (blockIdx.x / tiles_x) * OR_, x0 = (blockIdx.x % tiles_x) * OC;
+    const int y0 = (bx_ / tiles_x) * OR_, x0 = (bx_ % tiles_x) * OC;
     const int HW = p.H * p.W;
     const float* in_b = p.in + (size_t)b * p.in_bs;
     const float* sc = PRO ? p.pro_scale : nullptr;
@@ -671,7 +672,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
     }
 #ifdef LASS_CONV_DIAG
     if (p.dbg && tid == 0) {
-        long long* d = p.dbg + 12 * ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+        long long* d = p.dbg + 12 * (size_t)blockIdx.x;
         for (int i = 0; i < 6; ++i) d[i] = dg[i];
         const long long k_end = clock64();
         d[6] = k_end - k_c0;
@@ -731,21 +732,25 @@ hipError_t launch_wino_v(const ConvArgs& p0, hipStream_t stream) {
     p.exp = exp_flags;
 #endif
     const bool wide = p.N % 64 == 0;  // 32-cout blocks on the >= 64-cout layers: measured 10 % slower (V work doubles)
+    static const bool xcd = [] { const char* e = getenv("LASS_XCD_MAP"); return !e || atoi(e) != 0; }();
+    auto set_grid = [&](int gx, int gy) {  // 1-D grid, decoded by block_coords()
+        p.gx = gx; p.gy = gy;
+        p.xcd_map = (xcd && gy > 1 && ((long)gx * p.B) % 8 == 0) ? 1 : 0;
+        return dim3((unsigned)((long)gx * gy * p.B));
+    };
     if (p.W < 32) {  // 16- / 8-bin layers: 64-cout blocks of 8 x 16 or 16 x 8 output pixels
         if constexpr ((FLAGS & (F_MASK | F_PRECONV | F_RESPRE)) != 0) {
             return hipErrorInvalidValue;
         } else {
             if (!wide || (p.W != 16 && p.W != 8)) return hipErrorInvalidValue;
             if (p.W == 16)
-                hipLaunchKernelGGL((wino_kernel<2, 2, FLAGS, 8, PATCH>), dim3((p.H + 7) / 8, p.N / 64, p.B), dim3(NTHREADS), 0,
-                                   stream, p);
+                { const dim3 g8 = set_grid((p.H + 7) / 8, p.N / 64); hipLaunchKernelGGL((wino_kernel<2, 2, FLAGS, 8, PATCH>), g8, dim3(NTHREADS), 0, stream, p); }
             else
-                hipLaunchKernelGGL((wino_kernel<2, 2, FLAGS, 4, PATCH>), dim3((p.H + 15) / 16, p.N / 64, p.B), dim3(NTHREADS), 0,
-                                   stream, p);
+                { const dim3 g4 = set_grid((p.H + 15) / 16, p.N / 64); hipLaunchKernelGGL((wino_kernel<2, 2, FLAGS, 4, PATCH>), g4, dim3(NTHREADS), 0, stream, p); }
             return hipGetLastError();
         }
     }
-    dim3 grid = wide ? dim3((p.W / 32) * ((p.H + 3) / 4), p.N / 64, p.B) : dim3((p.W / 32) * ((p.H + 7) / 8), p.N / 32, p.B);
+    const dim3 grid = wide ? set_grid((p.W / 32) * ((p.H + 3) / 4), p.N / 64) : set_grid((p.W / 32) * ((p.H + 7) / 8), p.N / 32);
 #ifdef LASS_CONV_DIAG
     static long long* dbuf = nullptr;
     static size_t dcap = 0;

@@ -17,6 +17,27 @@ __device__ __forceinline__ void wait_vmcnt() {  // all but the N youngest vector
 
 typedef int v4i32 __attribute__((ext_vector_type(4)));
 
+// Workgroup -> (spatial tile bx, cout block by, clip bz) from a 1-D grid.  Workgroups are dealt round-robin over the 8
+// XCDs (each with its own L2), so with the natural order the gy cout blocks that re-read one input tile land on gy
+// different XCDs and the tile is fetched gy times from HBM.  With xcd_map the gy blocks of a (tile, clip) pair are given
+// linear ids that are equal mod 8: same XCD, the re-reads hit its L2.  (Speed only: nothing depends on the placement.)
+__device__ __forceinline__ void block_coords(const ConvArgs& p, int& bx, int& by, int& bz) {
+    const unsigned lin = blockIdx.x;
+    unsigned xz, y;
+    if (p.xcd_map) {
+        const unsigned q = lin & 7u, s = lin >> 3;
+        const unsigned g = s / (unsigned)p.gy;
+        y = s - g * (unsigned)p.gy;
+        xz = g * 8u + q;
+    } else {
+        xz = lin / (unsigned)p.gy;
+        y = lin - xz * (unsigned)p.gy;
+    }
+    bz = (int)(xz / (unsigned)p.gx);
+    bx = (int)(xz - (unsigned)bz * (unsigned)p.gx);
+    by = (int)y;
+}
+
 // Buffer descriptor words for inline-asm buffer ops (raw buffer, stride 0, `bytes` records), from wave-uniform inputs.
 __device__ __forceinline__ v4i32 make_rsrc_words(const void* base, unsigned bytes) {
     const unsigned long long a = (unsigned long long)base;
