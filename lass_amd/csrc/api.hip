@@ -118,9 +118,19 @@ struct lass_ctx {
             return mix == o.mix && cond == o.cond && out == o.out && ws == o.ws && B == o.B && L == o.L && gen == o.gen;
         }
     };
-    GraphKey g_key, g_seen;        // key of the instantiated graph / of the previous call
-    int g_seen_count = 0;          // consecutive eager calls with g_seen
-    hipGraphExec_t g_exec = nullptr;
+    // A small cache of instantiated graphs: the evaluator alternates between its common batch and a ragged tail, long-form
+    // callers between a few window counts.  An entry is captured on the third call that presents its key.
+    struct GraphEntry {
+        GraphKey key;
+        hipGraphExec_t exec = nullptr;
+        int seen = 0;            // calls with this key so far
+        unsigned long used = 0;  // g_tick of the last call (LRU)
+    };
+    static constexpr int kGraphSlots = 4;
+    GraphEntry g_slots[kGraphSlots];
+    unsigned long g_tick = 0;
+    std::vector<hipGraphExec_t> g_retired;  // replaced execs: a replay may still be in flight on some stream, so they are
+                                            // destroyed only behind a device synchronisation (lass_finalize / lass_destroy)
     hipStream_t g_stream = nullptr;
     unsigned long gen = 0;         // bumped by lass_finalize: a graph holds weight pointers
     long g_replays = 0, g_captures = 0;
@@ -583,6 +593,16 @@ int check_ready(lass_ctx* c) {
     return use_device(c);
 }
 
+// Destroys every instantiated graph (live and retired).  Caller has synchronised the device.
+void drop_graphs(lass_ctx* c) {
+    for (auto& e : c->g_slots) {
+        if (e.exec) (void)hipGraphExecDestroy(e.exec);
+        e = lass_ctx::GraphEntry();
+    }
+    for (hipGraphExec_t x : c->g_retired) (void)hipGraphExecDestroy(x);
+    c->g_retired.clear();
+}
+
 const ResBlock* find_block(const lass_ctx* c, const std::string& prefix) {
     for (const auto& rb : c->enc) if (rb.prefix == prefix) return &rb;
     for (const auto& rb : c->dec) if (rb.prefix == prefix) return &rb;
@@ -695,7 +715,8 @@ int lass_destroy(lass_ctx* c) {
     free_owned(c);
     for (auto& kv : c->raw) (void)hipFree(kv.second.d);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
-    if (c->g_exec) (void)hipGraphExecDestroy(c->g_exec);
+    (void)hipDeviceSynchronize();  // no replay of a graph below is in flight any more
+    drop_graphs(c);
     if (c->g_stream) (void)hipStreamDestroy(c->g_stream);
     (void)hipFree(c->tw2k);
     delete c;
@@ -739,6 +760,8 @@ int lass_finalize(lass_ctx* c, int compute_mode) {
         return fail(c, LASS_ERR_ARG, "the multi-STFT model computes in f32 only");
     c->compute_mode = compute_mode;
     HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipDeviceSynchronize());  // replays of graphs that hold the old derived buffers have drained
+    drop_graphs(c);
     free_owned(c);
     c->finalized = false;
     hipStream_t st = nullptr;
@@ -1272,47 +1295,61 @@ int lass_separate(lass_ctx* c, const float* mixture, const float* condition, flo
                   size_t workspace_bytes, void* stream) {
     if (!c) return LASS_ERR_ARG;
     if (!mixture) return fail(c, LASS_ERR_ARG, "lass_separate: null pointer");
-    // Graph replay: a call whose pointers and shape equal those of the two PREVIOUS calls is captured once (on an internal stream; the
+    // Graph replay: the third call that presents the same (pointers, shape) key is captured once (on an internal stream; the
     // caller's may be the legacy default stream, which cannot be captured) and replayed from then on.  Callers that hand
-    // over fresh buffers every time (the evaluator loop) simply stay on the eager path; so does a profiled context.
+    // over fresh buffers every time simply stay on the eager path; so does a profiled context.
     lass_ctx::GraphKey key;
     key.mix = mixture; key.cond = condition; key.out = out; key.ws = workspace; key.B = B; key.L = L; key.gen = c->gen;
+#ifdef LASS_CONV_DIAG
+    c->use_graph = false;  // the diagnostic launchers allocate and synchronise: not capturable
+#endif
     if (c->use_graph && !c->profiling && c->finalized) {
-        if (c->g_exec && key == c->g_key) {
+        ++c->g_tick;
+        lass_ctx::GraphEntry* slot = nullptr;
+        for (auto& e : c->g_slots)
+            if (e.seen > 0 && e.key == key) slot = &e;
+        if (!slot) {  // take the least recently used slot, preferring one without a graph
+            for (auto& e : c->g_slots)
+                if (!slot || (!e.exec && slot->exec) || (!e.exec == !slot->exec && e.used < slot->used)) slot = &e;
+            if (slot->exec) c->g_retired.push_back(slot->exec);  // may still be replaying: destroyed behind a device sync
+            *slot = lass_ctx::GraphEntry();
+            slot->key = key;
+        }
+        slot->used = c->g_tick;
+        ++slot->seen;
+        if (slot->exec) {
             HIP_TRY(c, hipSetDevice(c->device));
-            HIP_TRY(c, hipGraphLaunch(c->g_exec, (hipStream_t)stream));
+            HIP_TRY(c, hipGraphLaunch(slot->exec, (hipStream_t)stream));
             ++c->g_replays;
             return 0;
         }
-        if (key == c->g_seen && c->g_seen_count >= 2) {  // third identical call in a row: worth a capture
+        if (slot->seen >= 3) {  // worth a capture
             HIP_TRY(c, hipSetDevice(c->device));
             if (!c->g_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->g_stream, hipStreamNonBlocking));
-            if (c->g_exec) { (void)hipGraphExecDestroy(c->g_exec); c->g_exec = nullptr; }
+            bool ok = false;
             if (hipStreamBeginCapture(c->g_stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
                 const int r = separate_impl(c, mixture, nullptr, condition, out, B, L, workspace, workspace_bytes, c->g_stream,
                                             "lass_separate");
                 hipGraph_t graph = nullptr;
-                const hipError_t e = hipStreamEndCapture(c->g_stream, &graph);
-                if (r) { if (graph) (void)hipGraphDestroy(graph); return r; }
-                if (e == hipSuccess && graph && hipGraphInstantiate(&c->g_exec, graph, nullptr, nullptr, 0) == hipSuccess) {
-                    (void)hipGraphDestroy(graph);
-                    c->g_key = key;
-                    ++c->g_captures;
-                    HIP_TRY(c, hipGraphLaunch(c->g_exec, (hipStream_t)stream));
-                    return 0;
-                }
+                const hipError_t e = hipStreamEndCapture(c->g_stream, &graph);  // always ends the capture, also after a failure
+                if (r == 0 && e == hipSuccess && graph && hipGraphInstantiate(&slot->exec, graph, nullptr, nullptr, 0) == hipSuccess)
+                    ok = true;
+                else
+                    slot->exec = nullptr;
                 if (graph) (void)hipGraphDestroy(graph);
-                c->g_exec = nullptr;
-                (void)hipGetLastError();
-                c->use_graph = false;  // capture is not usable here: stay eager from now on
-            } else {
-                (void)hipGetLastError();
-                c->use_graph = false;
             }
+            if (ok) {
+                ++c->g_captures;
+                HIP_TRY(c, hipGraphLaunch(slot->exec, (hipStream_t)stream));
+                return 0;
+            }
+            // A launch failed inside the capture, or the runtime refused it: nothing has run yet.  Stay eager from now on and
+            // run this call eagerly below (an error is reported only if the eager run fails too).
+            (void)hipGetLastError();
+            c->use_graph = false;
+            c->err.clear();
         }
     }
-    c->g_seen_count = (key == c->g_seen) ? c->g_seen_count + 1 : 1;
-    c->g_seen = key;
     return separate_impl(c, mixture, nullptr, condition, out, B, L, workspace, workspace_bytes, stream, "lass_separate");
 }
 

@@ -46,7 +46,9 @@ class Engine:
         self.ctx = h
         self.n_fft = 1024 if multistft is None else self.multistft[0]
         self.n_branches = 1 if multistft is None else len(self.multistft[1])
-        self._ws: Dict[tuple, torch.Tensor] = {}
+        self._ws_buf: Optional[torch.Tensor] = None  # ONE workspace, as large as the largest (B, L) seen so far
+        self._ws_last = None                         # (B, L) of the last call that used it (its intermediates live there)
+        self.ws_allocations = 0
         self.finalized = False
 
     def __del__(self):
@@ -94,13 +96,17 @@ class Engine:
         return n.value
 
     def _workspace(self, B: int, L: int) -> torch.Tensor:
-        key = (B, L)
-        ws = self._ws.get(key)
-        if ws is None:
-            self._ws.clear()  # one live shape at a time: workspaces are GBs
-            ws = torch.empty(self.workspace_bytes(B, L), dtype=torch.uint8, device=self.device)
-            self._ws[key] = ws
-        return ws
+        """One buffer keyed on capacity: any (B, L) whose lass_workspace_bytes fits reuses it (lass_separate only needs
+        workspace_bytes >= its plan), so the evaluator's ragged last batch neither frees and re-allocates gigabytes nor
+        changes the workspace pointer the captured graph of the common batch is keyed on.  It grows when a larger shape
+        arrives (the old buffer is released first: workspaces are GBs)."""
+        need = self.workspace_bytes(B, L)
+        if self._ws_buf is None or self._ws_buf.numel() < need:
+            self._ws_buf = None
+            self._ws_buf = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self.ws_allocations += 1
+        self._ws_last = (B, L)
+        return self._ws_buf
 
     def separate(self, mixture: torch.Tensor, condition: torch.Tensor, out: Optional[torch.Tensor] = None):
         """mixture (B,L) f32, condition (B,512) f32 on this device -> (B,L) f32."""
@@ -269,9 +275,9 @@ class Engine:
         rc = self.lib.lass_workspace_tensor(self.ctx, B, L, name.encode(), byref(off), shape, strides)
         if rc < 0:
             raise _lib.LassError(f"lass_workspace_tensor: unknown tensor '{name}' or bad shape")
-        ws = self._ws.get((B, L))
+        ws = self._ws_buf if self._ws_last == (B, L) else None
         if ws is None:
-            raise _lib.LassError("no workspace of that shape: call separate(B, L) first")
+            raise _lib.LassError("the workspace does not hold a run of that shape: call separate(B, L) first")
         assert off.value % 4 == 0
         flat = ws.view(torch.float32)
         return flat.as_strided(tuple(shape), tuple(strides), off.value // 4)

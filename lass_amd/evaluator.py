@@ -30,6 +30,19 @@ from .utils import load_ss_model, parse_yaml
 from .wavio import read_wav
 
 
+def _mix_on_host(source: np.ndarray, noise: np.ndarray, snr_db: int):
+    """The evaluator's deterministic mixer (dcase_evaluator.py:77-89) in numpy: the noise is given the gain that puts the
+    pair at `snr_db` (power ratio of the two clips), and a mixture that would clip is brought down to a 0.9 peak together
+    with its source, so the SDR reference stays consistent with what the separator hears.  Returns (source, mixture);
+    `lass_mix_at_snr` is the device-side twin."""
+    gain = np.sqrt(np.mean(np.square(source)) / (10 ** (snr_db / 10)) / np.mean(np.square(noise)))
+    mixture = source + noise * gain
+    peak = np.max(np.abs(mixture))
+    if peak > 1:
+        source, mixture = source * (0.9 / peak), mixture * (0.9 / peak)
+    return source, mixture
+
+
 class DCASEEvaluator:
     def __init__(self, sampling_rate=16000, eval_indexes="lass_synthetic_validation.csv", audio_dir="lass_validation",
                  batch_size: int = 16, device_mixing: bool = True, io_workers: int = 4) -> None:
@@ -63,25 +76,11 @@ class DCASEEvaluator:
         return torch.stack([self._embed_cache[c] for c in captions])
 
     def _load_clip(self, eval_data):
-        """dcase_evaluator.py:67-89 for one csv row -> (source, mixture, caption), float32."""
-        source, noise, snr, caption = eval_data
-        snr = int(snr)
-        source, _ = read_wav(os.path.join(self.audio_dir, f"{source}.wav"), self.sampling_rate)
-        noise, _ = read_wav(os.path.join(self.audio_dir, f"{noise}.wav"), self.sampling_rate)
-        source = source.copy()
-        # scale the noise so that the pair sits at the row's SNR (dcase_evaluator.py:77-83)
-        source_power = np.mean(source ** 2)
-        noise_power = np.mean(noise ** 2)
-        desired_noise_power = source_power / (10 ** (snr / 10))
-        scaling_factor = np.sqrt(desired_noise_power / noise_power)
-        noise = noise * scaling_factor
-        mixture = source + noise
-        # a mixture that would clip is brought to a 0.9 peak together with its source (dcase_evaluator.py:86-89)
-        max_value = np.max(np.abs(mixture))
-        if max_value > 1:
-            source *= 0.9 / max_value
-            mixture *= 0.9 / max_value
-        return source.astype(np.float32), mixture.astype(np.float32), caption
+        """Host-side variant of the data path (`device_mixing=False`): decode one csv row's pair and mix it on the CPU
+        -> (source, mixture, caption), float32.  Semantics of dcase_evaluator.py:67-89."""
+        source, noise, snr_db, caption = self._read_pair(eval_data)
+        source, mixture = _mix_on_host(source, noise, snr_db)
+        return source.astype(np.float32, copy=False), mixture.astype(np.float32, copy=False), caption
 
     def __call__(self, pl_model) -> tuple:
         r"""Evaluate (dcase_evaluator.py:49-122)."""

@@ -5,7 +5,7 @@ Host-side mirror of the reference's pre-compute path:
   * `multi_resolution_stfts`         the loop at scripts/precompute_stfts.py:573-590, as ONE kernel launch
   * `make_precomputed_items`         the per-item dict at scripts/precompute_stfts.py:596-622
   * `save_batch_precomputed_data`    scripts/precompute_stfts.py:60-122  (`batch_%06d.pt`: a list of dicts)
-  * `PrecomputedSTFTDataset`         data/precomputed_stft_dataset.py:7-134 (file scan, cumulative index, one-file cache)
+  * `PrecomputedSTFTDataset`         data/precomputed_stft_dataset.py:7-134 (interface: numeric shard order, global index)
 
 All spectra are computed by liblass_hip (`lass_multi_stft`, lass_amd/csrc/stft.hip); there is no CPU fallback.
 The consumer of these files in the reference (`models/resunet_with_multistft.py`) is not runnable as shipped
@@ -82,7 +82,9 @@ def make_precomputed_items(mixtures: torch.Tensor, segments: torch.Tensor, texts
         raise ValueError("mixtures and segments must have the same shape")
     mix = multi_resolution_stfts(mixtures, win_lengths, hop_length, window, center, pad_mode, n_fft)
     seg = multi_resolution_stfts(segments, win_lengths, hop_length, window, center, pad_mode, n_fft)
-    common = {"hop_length": hop_length, "window": window, "center": center, "pad_mode": pad_mode}
+    # "n_fft": None = every window at n_fft = win_length (what the reference writes); an int = the common transform size
+    # of the multi-STFT consumer.  The 2048 window has 1025 bins either way, so the shapes alone cannot tell the two apart.
+    common = {"hop_length": hop_length, "window": window, "center": center, "pad_mode": pad_mode, "n_fft": n_fft}
     items = []
     for k in range(mixtures.shape[0]):
         items.append({
@@ -113,7 +115,7 @@ def save_batch_precomputed_data(output_dir, batch_index: int, batch_data_list: L
     """scripts/precompute_stfts.py:60-122: one `batch_%06d.pt` per batch holding a list of CPU dicts; returns the number
     of items written (0 for an empty list: no file is created)."""
     if not batch_data_list:
-        print(f"Warning: Attempting to save empty data list for batch {batch_index}. Skipping file creation.")
+        print(f"save_batch_precomputed_data: batch {batch_index} is empty, no file written")
         return 0
     output_dir = pathlib.Path(output_dir)
     output_dir.mkdir(parents=True, exist_ok=True)
@@ -121,48 +123,68 @@ def save_batch_precomputed_data(output_dir, batch_index: int, batch_data_list: L
     return len(batch_data_list)
 
 
+class _Shard:
+    """One `batch_*.pt` file of the wire format: where it is and which global indices it serves."""
+    __slots__ = ("path", "first", "count")
+
+    def __init__(self, path: pathlib.Path, first: int, count: int):
+        self.path, self.first, self.count = path, first, count
+
+
+def _batch_number(path: pathlib.Path) -> int:
+    return int(path.stem.rsplit("_", 1)[1])
+
+
+def _read_shard(path: pathlib.Path) -> List[Dict[str, Any]]:
+    # weights_only=True: a shard holds tensors, strings, numbers, lists, tuples and dicts - nothing is executed
+    items = torch.load(path, map_location="cpu", weights_only=True)
+    if not isinstance(items, list) or not items:
+        raise ValueError("not a non-empty list of items")
+    return items
+
+
 class PrecomputedSTFTDataset(torch.utils.data.Dataset):
-    """data/precomputed_stft_dataset.py:7-134: items of all `batch_*.pt` files in numeric order, addressed by a global
-    index through cumulative counts, with the most recently opened file cached.  Files are opened with
-    `torch.load(weights_only=True)`: they hold only tensors, strings, numbers, lists, tuples and dicts."""
+    """Map-style dataset over a directory of `batch_*.pt` shards (interface of data/precomputed_stft_dataset.py:7-134):
+    `len()` is the number of items of all readable shards, `ds[i]` the i-th item counting through the shards in NUMERIC
+    batch order.  Unreadable or empty shards are reported on stdout and left out.  Only the shard touched last stays in
+    memory, so a sequential sweep reads every file once."""
 
     def __init__(self, data_dir: str, expected_num_items: Optional[int] = None):
-        self.data_dir = pathlib.Path(data_dir)
-        if not self.data_dir.is_dir():
-            raise FileNotFoundError(f"Data directory not found: {self.data_dir}")
-        self.file_paths: List[pathlib.Path] = []
-        self.item_counts: List[int] = []
-        self.cumulative_counts: List[int] = [0]
-        for path in sorted(self.data_dir.glob("batch_*.pt"), key=lambda p: int(p.stem.split("_")[-1])):
+        root = pathlib.Path(data_dir)
+        if not root.is_dir():
+            raise FileNotFoundError(f"no such directory of precomputed STFT shards: {root}")
+        self.data_dir = root
+        self._shards: List[_Shard] = []
+        n = 0
+        for path in sorted(root.glob("batch_*.pt"), key=_batch_number):
             try:
-                loaded = torch.load(path, map_location="cpu", weights_only=True)
-            except Exception as e:  # same policy as the reference: report and skip
-                print(f"Warning: Failed to load or process {path}. Skipping. Error: {e}")
+                count = len(_read_shard(path))
+            except Exception as err:
+                print(f"PrecomputedSTFTDataset: leaving out {path.name} ({err})")
                 continue
-            if not isinstance(loaded, list) or not loaded:
-                print(f"Warning: {path} does not hold a non-empty list. Skipping.")
-                continue
-            self.file_paths.append(path)
-            self.item_counts.append(len(loaded))
-            self.cumulative_counts.append(self.cumulative_counts[-1] + len(loaded))
-        self.total_items = self.cumulative_counts[-1]
-        if expected_num_items is not None and self.total_items != expected_num_items:
-            print(f"Warning: Found {self.total_items} items, but expected {expected_num_items}.")
-        self._cached_file_idx: Optional[int] = None
-        self._cached_data: Optional[List[Dict]] = None
+            self._shards.append(_Shard(path, n, count))
+            n += count
+        self._starts = [sh.first for sh in self._shards]
+        self._size = n
+        self._open: Optional[tuple] = None  # (shard position, its items)
+        if expected_num_items is not None and expected_num_items != n:
+            print(f"PrecomputedSTFTDataset: {n} items under {root}, {expected_num_items} were expected")
+
+    @property
+    def shard_sizes(self) -> List[int]:
+        return [sh.count for sh in self._shards]
 
     def __len__(self) -> int:
-        return self.total_items
+        return self._size
 
     def __getitem__(self, idx: int) -> Dict[str, Any]:
-        if not 0 <= idx < self.total_items:
-            raise IndexError(f"Index {idx} out of bounds for dataset with size {self.total_items}")
-        file_idx = bisect.bisect_right(self.cumulative_counts, idx) - 1
-        if file_idx != self._cached_file_idx or self._cached_data is None:
+        if idx < 0 or idx >= self._size:
+            raise IndexError(f"item {idx} requested from a PrecomputedSTFTDataset of {self._size} items")
+        pos = bisect.bisect_right(self._starts, idx) - 1
+        if self._open is None or self._open[0] != pos:
+            self._open = None
             try:
-                self._cached_data = torch.load(self.file_paths[file_idx], map_location="cpu", weights_only=True)
-                self._cached_file_idx = file_idx
-            except Exception as e:
-                self._cached_data, self._cached_file_idx = None, None
-                raise RuntimeError(f"Failed to load data file {self.file_paths[file_idx]}: {e}")
-        return self._cached_data[idx - self.cumulative_counts[file_idx]]
+                self._open = (pos, _read_shard(self._shards[pos].path))
+            except Exception as err:
+                raise RuntimeError(f"shard {self._shards[pos].path} became unreadable: {err}") from err
+        return self._open[1][idx - self._shards[pos].first]

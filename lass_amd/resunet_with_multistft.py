@@ -69,6 +69,13 @@ class ResUNet30(_ResUNet30):
                 t = t.squeeze(1)
             return t.to(device=dev, dtype=torch.float32)[:, 0].contiguous()
 
+        nb = arch.MS_N_BINS
+        for w in self.win_lengths:  # files written with n_fft = win_length (the reference's own writer) have w//2+1 bins
+            got = input_dict["stft_mixture_mag"][w].shape[-1]
+            if got != nb:
+                raise ValueError(f"window {w}: {got} bins; this model reads spectra at the common n_fft = {arch.MS_N_FFT} "
+                                 f"({nb} bins per window) - write them with make_precomputed_items(..., n_fft={arch.MS_N_FFT}) "
+                                 "(stft_common_params['n_fft'] records it)")
         mags = [plane(input_dict["stft_mixture_mag"], w) for w in self.win_lengths]
         cos = plane(input_dict["stft_mixture_cos"], arch.MS_MASK_WINDOW)
         sin = plane(input_dict["stft_mixture_sin"], arch.MS_MASK_WINDOW)

@@ -214,20 +214,38 @@ def test_separate_tiny_vs_oracle_and_golden(model, oracle_sd, golden_dir):
     assert _rms(out.cpu() - torch.from_numpy(g["waveform"])) < 2e-6   # the reference's own output
 
 
-def test_separate_10s_vs_golden(model, golden_dir):
+@pytest.mark.parametrize("mode", ["f32", "bf16x3", "bf16"])
+def test_separate_10s_vs_golden(synthetic_sd, golden_dir, mode):
+    """G2 = the reference's own output and SDR / SDRi / SI-SDR triple on a 10 s clip (tools/gen_golden.py).  Every compute
+    mode is pinned to it: the triple within north_star's 0.05 dB (f32: 0.01), the waveform within 3e-6 RMS for f32,
+    1e-5 RMS for the split-operand mode (f32 tolerance class), 5 % relative for plain bf16 (8-bit mantissa operands)."""
+    from lass_amd.resunet import ResUNet30
     from oracle import metrics as om
     g = np.load(os.path.join(golden_dir, "g2_clip10s.npz"))
     src, mix = synthetic.make_mixtures(1, 160000, first=3)
     cond = synthetic.make_condition(1)
-    out = model({"mixture": torch.from_numpy(mix)[:, None, :].to(DEV), "condition": torch.from_numpy(cond).to(DEV)})[
+    m = ResUNet30(1, 1, 512)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synthetic_sd.items()})
+    m = m.to(DEV).eval().set_compute_dtype(mode)
+    out = m({"mixture": torch.from_numpy(mix)[:, None, :].to(DEV), "condition": torch.from_numpy(cond).to(DEV)})[
         "waveform"][0, 0].cpu().numpy()
-    assert np.sqrt(np.mean((out[::16] - g["waveform_dec"]) ** 2)) < 3e-6
-    np.testing.assert_allclose(out[:2048], g["head"], atol=3e-5)
-    np.testing.assert_allclose(out[-2048:], g["tail"], atol=3e-5)
+    err = float(np.sqrt(np.mean((out[::16] - g["waveform_dec"]) ** 2)))
+    ref_rms = float(np.sqrt(np.mean(g["waveform_dec"] ** 2)))
+    print(mode, "waveform RMS error vs the reference's own 10 s output", err, "relative", err / ref_rms)
+    if mode == "f32":
+        assert err < 3e-6
+        np.testing.assert_allclose(out[:2048], g["head"], atol=3e-5)
+        np.testing.assert_allclose(out[-2048:], g["tail"], atol=3e-5)
+    elif mode == "bf16x3":
+        assert err <= 1e-5
+    else:
+        assert 1e-7 < err < 5e-2 * ref_rms   # really the bf16 kernels, and sane
     sdr = om.calculate_sdr(src[0], out)
     sdr0 = om.calculate_sdr(src[0], mix[0])
     sisdr = om.calculate_sisdr(src[0], out)
-    np.testing.assert_allclose([sdr, sdr - sdr0, sisdr], g["sdr_triple"], atol=0.01)   # bar: +-0.05 dB
+    got = np.asarray([sdr, sdr - sdr0, sisdr])
+    print(mode, "SDR / SDRi / SI-SDR", got, "reference", g["sdr_triple"])
+    np.testing.assert_allclose(got, g["sdr_triple"], atol=0.01 if mode == "f32" else 0.05)   # bar: +-0.05 dB
 
 
 def test_separate_batch_invariance_full_size(model):

@@ -219,3 +219,36 @@ def test_graph_replay_equals_eager(synthetic_sd, monkeypatch):
     for _ in range(3):
         y = eng.separate(torch.from_numpy(mix[:B]).to(DEV).clone(), cond)
     assert torch.equal(y, outs[0]) and eng.graph_stats()[1] <= caps_before + 1
+
+
+def test_workspace_reuse_and_graphs_across_ragged_batches(synthetic_sd):
+    """The evaluator's pattern (dcase_evaluator.py:65-116 batched): the common batch B=16... and a ragged tail.  The smaller
+    shape must reuse the ONE workspace allocation (lass_separate only needs workspace_bytes >= its plan), so the workspace
+    pointer - part of the graph key - is stable, both shapes keep their captured graph (<= 2 captures however often they
+    alternate), and results equal fresh eager runs."""
+    from lass_amd.resunet import ResUNet30
+    m = ResUNet30(1, 1, 512)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synthetic_sd.items()})
+    eng = m.to(DEV).eval().engine
+    L = 24000
+    _, mix = synthetic.make_mixtures(16, L)
+    xs = {16: torch.from_numpy(mix).to(DEV), 5: torch.from_numpy(mix[:5]).to(DEV)}
+    cs = {b: torch.from_numpy(synthetic.make_condition(b)).to(DEV) for b in xs}
+    os_ = {b: torch.empty_like(xs[b]) for b in xs}
+    first = {}
+    for rnd in range(4):
+        for b in (16, 5):
+            eng.separate(xs[b], cs[b], os_[b])
+            if rnd == 0:
+                first[b] = os_[b].clone()
+            else:
+                assert torch.equal(os_[b], first[b]), (rnd, b)
+    on, caps, reps = eng.graph_stats()
+    assert eng.ws_allocations == 1
+    assert on and caps == 2 and reps == 2, (on, caps, reps)   # per shape: eager, eager, capture, replay
+    assert torch.equal(first[5], first[16][:5])                # clips are independent of their batch
+    # a larger shape grows the buffer once; the small ones keep working in it
+    big = eng.separate(torch.from_numpy(synthetic.make_mixtures(2, 2 * 16 * L // 2)[1]).to(DEV),
+                       torch.from_numpy(synthetic.make_condition(2)).to(DEV))
+    assert torch.isfinite(big).all() and eng.ws_allocations <= 2
+    assert torch.equal(eng.separate(xs[5], cs[5]), first[5])

@@ -63,7 +63,8 @@ m = ResUNet30(1, 1, 512)
 m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
 m = m.to("cuda:0").eval()
 pl_model = AudioSep(ss_model=m, query_encoder=PrecomputedQueryEncoder())
-ev = DCASEEvaluator(sampling_rate=16000, eval_indexes=csv_path, audio_dir=audio_dir, batch_size=3)
+ev = DCASEEvaluator(sampling_rate=16000, eval_indexes=csv_path, audio_dir=audio_dir,
+                    batch_size=int(sys.argv[5]) if len(sys.argv) > 5 else 3)
 res = ev(pl_model)
 np.save(os.path.join(out_dir, f"rows_rank{rank}.npy"), ev.last_rows)
 np.save(os.path.join(out_dir, f"means_rank{rank}.npy"), np.asarray(res))
@@ -103,6 +104,51 @@ def test_sharded_evaluator_two_ranks_equals_single_rank(tmp_path):
         # not see (eval-mode BN: no cross-clip coupling) -> bit-identical rows
         np.testing.assert_allclose(rows, ev.last_rows, rtol=0, atol=1e-9)
         np.testing.assert_allclose(means, single, rtol=0, atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_configs3_workload_128_clips_two_ranks(tmp_path):
+    """BASELINE configs[3] at its stated size: 128 clips of 10 s @ 16 kHz through DCASEEvaluator.__call__
+    (dcase_evaluator.py:65-122) in 16-clip batches, clip-sharded over 2 rank processes (64 clips = four batches each; both
+    on cuda:0, backend gloo - RCCL refuses two ranks on one device), one all-gather of the metric rows.  The gathered rows
+    and means equal the world-size-1 run, and 4 sampled clips equal the CPU oracle's evaluator to 0.01 dB."""
+    from lass_amd import synthetic
+    from lass_amd.audiosep import AudioSep, PrecomputedQueryEncoder
+    from lass_amd.evaluator import DCASEEvaluator
+    from lass_amd.resunet import ResUNet30
+    from oracle import evaluator as oev
+    from oracle import resunet as orr
+    n, L = 128, 160000
+    csv_path = synthetic.write_validation_set(str(tmp_path), n_clips=n, length=L)
+    audio_dir = os.path.join(str(tmp_path), "lass_validation")
+    script = os.path.join(str(tmp_path), "w.py")
+    open(script, "w").write(_EVAL_WORKER)
+    port = 31500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), script, ROOT, csv_path, audio_dir, str(tmp_path), "16"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=_env())
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    sd = synthetic.make_state_dict()
+    m = ResUNet30(1, 1, 512)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    m = m.to("cuda:0").eval()
+    qe = PrecomputedQueryEncoder()
+    ev = DCASEEvaluator(sampling_rate=16000, eval_indexes=csv_path, audio_dir=audio_dir, batch_size=16)
+    single = np.asarray(ev(AudioSep(ss_model=m, query_encoder=qe)))
+    assert ev.last_rows.shape == (n, 3) and np.isfinite(ev.last_rows).all()
+    for rank in (0, 1):
+        rows = np.load(os.path.join(str(tmp_path), f"rows_rank{rank}.npy"))
+        means = np.load(os.path.join(str(tmp_path), f"means_rank{rank}.npy"))
+        assert rows.shape == (n, 3) and not np.isnan(rows).any()
+        np.testing.assert_allclose(rows, ev.last_rows, rtol=0, atol=1e-9)
+        np.testing.assert_allclose(means, single, rtol=0, atol=1e-9)
+    # the CPU oracle's evaluator on clips from both shards (first / last batch of each)
+    picks = [0, 37, 64, 127]
+    clips = [synthetic.make_clip(i, L) for i in picks]
+    conds = qe.get_query_embed(modality="text", text=[f"synthetic tone cluster {i % 4}" for i in picks]).numpy()
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    _, orows = oev.evaluate(orr.to_torch(sd), clips, conds)
+    np.testing.assert_allclose(ev.last_rows[picks], orows, rtol=0, atol=0.01)
 
 
 def _bench_json(args, timeout=900):

@@ -50,7 +50,7 @@ def test_wire_format_roundtrip_and_dataset_index(tmp_path):
                                                      "stft_common_params", "stft_win_lengths"}
     assert set(raw[0]["stfts"]) == {"mixture", "segment"} and list(raw[0]["stfts"]["mixture"]) == WINS
     ds = ps.PrecomputedSTFTDataset(str(tmp_path), expected_num_items=5)
-    assert len(ds) == 5 and ds.cumulative_counts == [0, 3, 5]
+    assert len(ds) == 5 and ds.shard_sizes == [3, 2]
     for idx, src in enumerate(a + b):
         it = ds[idx]
         assert it["text"] == src["text"] and it["mixture_component_texts"] == src["mixture_component_texts"]

@@ -1,4 +1,4 @@
-# A/B of two library builds on the same box: usage bash tools/r2_ab.sh TAG libA.so libB.so
+# A/B of two library builds on the same box: usage: bash tools/gpu_ab.sh TAG libA.so libB.so
 TAG=$1; O=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $O; cd $GRAFT_REPO_ROOT
 for L in $2 $3; do
   echo "== $L"

@@ -11,7 +11,10 @@ Usage: traffic_summary.py fetch.csv write.csv out.json dtype [fetch_calibration.
 import collections
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def per_dispatch(path, counter):
@@ -54,6 +57,7 @@ def main(fetch_csv, write_csv, out_json, dtype, calib_json=None, launches_per_st
         "fetch_calibration": {"fetch_ratio": ratio_f, "write_ratio": ratio_w,
                               "source": calib_json or "MI355X_MICROARCH.md (0.5 / 1.0)"},
         "workload": "bench.py --steps 1 --warmup 1 (B=16, 10 s clips), last step",
+        "source_hash": __import__("__graft_entry__")._src_hash(),  # kernel sources this was measured at (bench.py checks it)
         "note": "L2 memory-side request bytes (Infinity-Cache hits included), corrected by the measured counter ratio",
     }
     json.dump(res, open(out_json, 'w'), indent=1)
