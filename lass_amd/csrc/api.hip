@@ -51,6 +51,7 @@ struct ResBlock {  // one ConvBlockRes
     int s1 = -1, s2 = -1;  // site indices
     float *w1 = nullptr, *w2 = nullptr, *wsc = nullptr;  // re-laid-out
     float *u1 = nullptr, *u2 = nullptr, *usc = nullptr;  // Winograd-domain copies (when enabled)
+    float *u1r = nullptr, *u2r = nullptr, *uscr = nullptr;  // 32-cout blocks: resident LDS images of wino32.hip
     void *b1 = nullptr, *b2 = nullptr, *bsc16 = nullptr;  // bf16 copies (LASS_COMPUTE_BF16 / _BF16X3)
     void *b1l = nullptr, *b2l = nullptr, *bscl = nullptr;  // lo halves of the hi+lo split (LASS_COMPUTE_BF16X3)
     const float* bsc = nullptr;                         // raw shortcut bias
@@ -103,6 +104,7 @@ struct lass_ctx {
     // profiling
     int compute_mode = LASS_COMPUTE_F32;
     bool wino = true;          // Winograd F(2x2,3x3) kernels for the 3x3 convs at W >= 32 (LASS_WINO=0: direct only)
+    bool wino32 = true;        // weights-resident persistent kernel for the 32-cout layers (LASS_WINO32=0: wino.hip everywhere)
     bool fuse_preconv = true;  // LASS_FUSE_PRECONV=0 materialises pre_conv's output with its own kernel
     bool fuse_pool = true;  // LASS_FUSE_POOL=0 selects the stand-alone pool kernel (A/B + parity of both paths)
     bool fuse_catb = true;  // bf16 mode: decoder concats as blocked bf16 copies (LASS_FUSE_CATB=0: f32 concat)
@@ -412,7 +414,7 @@ int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int
         p.in = x0; p.in_bs = HW;
         p.pre_w = pre->w; p.pre_b = pre->b;
     }
-    p.w_wino = rb.u1;
+    p.w_wino = rb.u1; p.w_wino32 = rb.u1r;
     p.w_bf16 = rb.b1; p.w_bf16_lo = rb.b1l;
     const bool bf1 = c->compute_mode != LASS_COMPUTE_F32 && rb.b1 && rb.b2 && lass_bf16_supported(p) &&
                      (!x0 || W % 32 == 0) && rb.cout % 16 == 0 && (rb.cin == rb.cout || (rb.bsc16 && rb.cin % 16 == 0));
@@ -428,6 +430,8 @@ int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int
         ProfScope ps(c, st, P_CONV3X3);
         if (bf1)
             HIP_TRY(c, lass_launch_conv_bf16(x0 ? CONV1_ACT_PRE : CONV1_ACT, p, st));
+        else if (wino1 && c->wino32 && lass_wino32_supported(x0 ? CONV1_ACT_PRE : CONV1_ACT, p))
+            HIP_TRY(c, lass_launch_wino32(x0 ? CONV1_ACT_PRE : CONV1_ACT, p, st));
         else if (wino1)
             HIP_TRY(c, lass_launch_wino(x0 ? CONV1_ACT_PRE : CONV1_ACT, p, st));
         else
@@ -437,7 +441,7 @@ int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int
     q.in = a2; q.in_bs = rb.cout * HW; q.Cin = rb.cout; q.w = rb.w2; q.Nw = rb.cout; q.N = rb.cout;
     q.out = out; q.out_bs = out_bs; q.B = B; q.H = H; q.W = W;
     q.pool_out = pool_out; q.pool_h = pool_h; q.pool_bs = pool_bs;
-    q.w_wino = rb.u2; q.w2_wino = rb.usc;
+    q.w_wino = rb.u2; q.w2_wino = rb.usc; q.w_wino32 = rb.u2r; q.w2_wino32 = rb.uscr;
     if (mh) {  // the block output is consumed by the fused head and never written
         q.out = nullptr;
         q.mask_w = rawp(c, "base.after_conv.weight"); q.mask_b = rawp(c, "base.after_conv.bias");
@@ -477,6 +481,8 @@ int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int
         }
         if (bf2)
             HIP_TRY(c, lass_launch_conv_bf16(x0 ? CONV2_IDENT_PRE : CONV2_IDENT, q, st));
+        else if (wino2 && c->wino32 && lass_wino32_supported(x0 ? CONV2_IDENT_PRE : CONV2_IDENT, q))
+            HIP_TRY(c, lass_launch_wino32(x0 ? CONV2_IDENT_PRE : CONV2_IDENT, q, st));
         else if (wino2)
             HIP_TRY(c, lass_launch_wino(x0 ? CONV2_IDENT_PRE : CONV2_IDENT, q, st));
         else
@@ -485,6 +491,8 @@ int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int
         q.in2 = x; q.in2_bs = x_bs; q.Cin2 = rb.cin; q.w2 = rb.wsc; q.bias = rb.bsc;
         if (bf2)
             HIP_TRY(c, lass_launch_conv_bf16(CONV2_SHORTCUT, q, st));
+        else if (wino2 && c->wino32 && lass_wino32_supported(CONV2_SHORTCUT, q))
+            HIP_TRY(c, lass_launch_wino32(CONV2_SHORTCUT, q, st));
         else if (wino2)
             HIP_TRY(c, lass_launch_wino(CONV2_SHORTCUT, q, st));
         else
@@ -645,6 +653,7 @@ static int create_impl(lass_ctx** out, int device_id, const Geometry& geom) {
     c->device = device_id;
     c->g = geom;
     if (const char* e = getenv("LASS_WINO")) c->wino = atoi(e) != 0;
+    if (const char* e = getenv("LASS_WINO32")) c->wino32 = atoi(e) != 0;
     if (const char* e = getenv("LASS_FUSE_POOL")) c->fuse_pool = atoi(e) != 0;
     if (const char* e = getenv("LASS_FUSE_MASK")) c->fuse_mask = atoi(e) != 0;
     if (const char* e = getenv("LASS_FUSE_CATB")) c->fuse_catb = atoi(e) != 0;
@@ -804,6 +813,7 @@ int lass_finalize(lass_ctx* c, int compute_mode) {
         HIP_TRY(c, lass_launch_relayout_conv(w1, rb.cout, rb.cin, 9, rb.w1, st));
         HIP_TRY(c, lass_launch_relayout_conv(w2, rb.cout, rb.cout, 9, rb.w2, st));
         rb.u1 = rb.u2 = rb.usc = nullptr;
+        rb.u1r = rb.u2r = rb.uscr = nullptr;
         rb.b1 = rb.b2 = rb.bsc16 = rb.b1l = rb.b2l = rb.bscl = nullptr;
         const bool bfm = c->compute_mode == LASS_COMPUTE_BF16 || c->compute_mode == LASS_COMPUTE_BF16X3;
         const bool split = c->compute_mode == LASS_COMPUTE_BF16X3;
@@ -828,6 +838,11 @@ int lass_finalize(lass_ctx* c, int compute_mode) {
                 return LASS_ERR_HIP;
             HIP_TRY(c, lass_launch_wino_weights(w1, rb.cout, rb.cin, rb.u1, st));
             HIP_TRY(c, lass_launch_wino_weights(w2, rb.cout, rb.cout, rb.u2, st));
+            if (rb.cout == 32 && rb.cin % 8 == 0) {  // full-resolution 32-channel blocks: wino32.hip
+                if (dev_alloc(c, &rb.u1r, (size_t)512 * rb.cin) || dev_alloc(c, &rb.u2r, (size_t)512 * rb.cout)) return LASS_ERR_HIP;
+                HIP_TRY(c, lass_launch_wino32_weights(w1, rb.cin, rb.u1r, st));
+                HIP_TRY(c, lass_launch_wino32_weights(w2, rb.cout, rb.u2r, st));
+            }
         }
         rb.wsc = nullptr;
         rb.bsc = nullptr;
@@ -852,6 +867,10 @@ int lass_finalize(lass_ctx* c, int compute_mode) {
             if (c->wino && c->compute_mode == LASS_COMPUTE_F32) {
                 if (dev_alloc(c, &rb.usc, (size_t)4 * rb.cout * rb.cin)) return LASS_ERR_HIP;
                 HIP_TRY(c, lass_launch_wino_shortcut_weights(ws, rb.cout, rb.cin, rb.usc, st));
+                if (rb.cout == 32 && rb.cin % 8 == 0) {
+                    if (dev_alloc(c, &rb.uscr, (size_t)128 * rb.cin)) return LASS_ERR_HIP;
+                    HIP_TRY(c, lass_launch_wino32_shortcut_weights(ws, rb.cin, rb.uscr, st));
+                }
             }
         }
         return 0;

@@ -40,6 +40,8 @@ struct ConvArgs {
     int up_h = 1;  // TCONV: vertical stride (1 or 2); horizontal stride is always 2
     const float* w_wino = nullptr;   // Winograd-domain weights U[16][Cin][Nw] (wino.hip)
     const float* w2_wino = nullptr;  // Winograd-domain shortcut weights [4][Cin2][Nw]
+    const float* w_wino32 = nullptr;   // 32-cout layers: the resident LDS image of wino32.hip (Cin * 512 floats)
+    const float* w2_wino32 = nullptr;  // ... of the shortcut weights (Cin2 * 128 floats)
     const void* w_bf16 = nullptr;    // bf16 weights [Cin/16][tap][2][Nw][8] (conv_bf16.hip)
     const void* w2_bf16 = nullptr;   // bf16 shortcut weights [Cin2/16][1][2][Nw][8]
     const void* w_bf16_lo = nullptr;   // split mode: bf16(w - float(bf16(w))), same layouts; non-null selects the 3-MFMA kernels
@@ -98,6 +100,12 @@ bool lass_wino_supported(const ConvArgs& p);
 hipError_t lass_launch_wino(ConvKind kind, const ConvArgs& p, hipStream_t stream);
 hipError_t lass_launch_wino_weights(const float* w, int Cout, int Cin, float* U, hipStream_t stream);
 hipError_t lass_launch_wino_shortcut_weights(const float* w, int Cout, int Cin, float* U, hipStream_t stream);
+
+// ---- wino32.hip (the 32-cout full-resolution layers: weights resident in LDS, persistent, waves decoupled) ------------
+bool lass_wino32_supported(ConvKind kind, const ConvArgs& p);
+hipError_t lass_launch_wino32(ConvKind kind, const ConvArgs& p, hipStream_t stream);
+hipError_t lass_launch_wino32_weights(const float* w, int Cin, float* U, hipStream_t stream);            // w (32, Cin, 3, 3)
+hipError_t lass_launch_wino32_shortcut_weights(const float* w, int Cin, float* U, hipStream_t stream);   // w (32, Cin, 1, 1)
 
 // ---- conv_bf16.hip (bf16-MFMA variant of the 3x3 kinds; W multiple of 32, Cin multiple of 16) ----------------------
 bool lass_bf16_supported(const ConvArgs& p);

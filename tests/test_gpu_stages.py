@@ -252,3 +252,39 @@ def test_workspace_reuse_and_graphs_across_ragged_batches(synthetic_sd):
                        torch.from_numpy(synthetic.make_condition(2)).to(DEV))
     assert torch.isfinite(big).all() and eng.ws_allocations <= 2
     assert torch.equal(eng.separate(xs[5], cs[5]), first[5])
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 40, 64), (3, 18, 32), (1, 64, 96)])
+def test_wino32_resident_kernel_vs_oracle_and_wino(synthetic_sd, oracle_sd, monkeypatch, B, H, W):
+    """wino32.hip (weights-resident persistent kernel of the 32-cout full-resolution layers, resunet.py:147-165 at the
+    shapes of :315-323,408-418) against the oracle and against wino.hip (LASS_WINO32=0), block by block: encoder_block1 with
+    its fused avg-pool (CONV1_ACT / CONV2_IDENT), decoder_block6's ConvBlockRes (Cin = 64 conv1, conv2 + transform-domain
+    shortcut).  Shapes cover border-only images (one block column), strips that do not fill a block of 8 (H/2 = 9, 20),
+    and B = 3."""
+    from lass_amd.engine import Engine
+    from oracle import resunet as orr
+    g = torch.Generator().manual_seed(H * W + B)
+    cond = torch.from_numpy(synthetic.make_condition(B))
+    outs = {}
+    for sw in ("1", "0"):
+        monkeypatch.setenv("LASS_WINO32", sw)
+        e = Engine(DEV)
+        e.load_state_dict(synthetic_sd)
+        monkeypatch.delenv("LASS_WINO32")
+        shift = e.film(cond.to(DEV))
+        x1 = torch.randn(B, 32, H, W, generator=g) if sw == "1" else x1
+        x6 = torch.randn(B, 64, H, W, generator=g) if sw == "1" else x6
+        y1, p1 = e.encoder_block("base.encoder_block1", x1.to(DEV), shift, 32, (2, 2))
+        y6 = e.convblock("base.decoder_block6.conv_block2", x6.to(DEV), shift, 32)
+        outs[sw] = (y1.cpu(), p1.cpu(), y6.cpu())
+    r1 = orr.conv_block_res(oracle_sd, "base.encoder_block1.conv_block1", x1,
+                            orr.film(oracle_sd, cond, "encoder_block1->conv_block1->beta1"),
+                            orr.film(oracle_sd, cond, "encoder_block1->conv_block1->beta2"))
+    r6 = orr.conv_block_res(oracle_sd, "base.decoder_block6.conv_block2", x6,
+                            orr.film(oracle_sd, cond, "decoder_block6->conv_block2->beta1"),
+                            orr.film(oracle_sd, cond, "decoder_block6->conv_block2->beta2"))
+    refs = (r1, torch.nn.functional.avg_pool2d(r1, (2, 2)), r6)
+    for got, old, ref in zip(outs["1"], outs["0"], refs):
+        assert got.shape == ref.shape
+        assert _relerr(got, ref) < 5e-6, _relerr(got, ref)     # the bar of test_convblock_vs_oracle
+        assert _relerr(got, old) < 2e-6, _relerr(got, old)     # same products, another summation order in B^T d B
