@@ -107,6 +107,73 @@ __device__ __forceinline__ void mfma_drain(f32x4 (&acc)[16][2]) {
                           "+v"(acc[xi + 2][1]), "+v"(acc[xi + 3][0]), "+v"(acc[xi + 3][1]));
 }
 
+typedef unsigned v2u32 __attribute__((ext_vector_type(2)));
+
+// Output transform Y = A^T M A and epilogue of one strip, written for instruction count (the vector instructions of the
+// epilogue are paid on top of the MFMA time like those of the K loop; wino_epilogue.h spends ~900 per strip, two thirds of
+// them on 64-bit addresses, selects for 16-byte stores and branches).  Every store is a buffer store: the lane part of the
+// address (its kq * 4 channels, its 2x2 tile) is ONE register per tensor, the channel (t, r) is a scalar offset; a tile row
+// is one 8-byte store (16 lanes = one 128-byte line).  Tables: (bias | epilogue scale, shift | pre_conv w, b) of channel n
+// at tb[n] / tb2[n] as float2.  H is even, so both rows of a tile are inside the image together.
+template <int FLAGS>
+__device__ __forceinline__ void w32_epilogue(const ConvArgs& p, f32x4 (&acc)[16][2], int b, int oy, int ox, int kq,
+                                             const float* lds_bias, const float2* lds_ep, const float2* lds_pre) {
+    constexpr bool EPI = (FLAGS & F_EPIACT) != 0, BIAS = (FLAGS & F_BIAS) != 0, RESPRE = (FLAGS & F_RESPRE) != 0;
+    const int HW = p.H * p.W;
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)b * p.out_bs, 0, (int)(32u * (unsigned)HW * 4u), 0x00020000);
+    const unsigned vo0 = (unsigned)(kq * 4 * HW + oy * p.W + ox) * 4u, vo1 = vo0 + (unsigned)p.W * 4u;
+    const bool pool = p.pool_out != nullptr;  // wave-uniform
+    const int Wo = p.W / 2, HWo = (p.H / 2) * Wo;
+    const size_t pool_bs = p.pool_bs ? (size_t)p.pool_bs : (size_t)32 * HWo;
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(pool ? p.pool_out + (size_t)b * pool_bs : p.out, 0,
+                                                                          pool ? (int)(32u * (unsigned)HWo * 4u) : 0, 0x00020000);
+    const unsigned vp = (unsigned)(kq * 4 * HWo + (oy >> 1) * Wo + (ox >> 1)) * 4u;
+    float2 x0r0 = make_float2(0.f, 0.f), x0r1 = x0r0;
+    if (RESPRE) {  // the residual is pre_conv(x0) (resunet.py:555,165): one 2x2 patch of x0 serves all 32 channels
+        const float* rp = p.res + (size_t)b * p.res_bs + (size_t)oy * p.W + ox;
+        x0r0 = *reinterpret_cast<const float2*>(rp);
+        x0r1 = *reinterpret_cast<const float2*>(rp + p.W);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = t * 16 + kq * 4 + r;
+            float s0[4], s1[4];
+#pragma unroll
+            for (int jx = 0; jx < 4; ++jx) {
+                s0[jx] = acc[0 + jx][t][r] + acc[4 + jx][t][r] + acc[8 + jx][t][r];
+                s1[jx] = acc[4 + jx][t][r] - acc[8 + jx][t][r] - acc[12 + jx][t][r];
+            }
+            float y00 = s0[0] + s0[1] + s0[2], y01 = s0[1] - s0[2] - s0[3];
+            float y10 = s1[0] + s1[1] + s1[2], y11 = s1[1] - s1[2] - s1[3];
+            if (BIAS) {
+                const float bb = lds_bias[n];
+                y00 += bb; y01 += bb; y10 += bb; y11 += bb;
+            }
+            if (RESPRE) {
+                const float2 w = lds_pre[n];
+                y00 += x0r0.x * w.x + w.y; y01 += x0r0.y * w.x + w.y;
+                y10 += x0r1.x * w.x + w.y; y11 += x0r1.y * w.x + w.y;
+            }
+            if (EPI) {
+                const float2 e = lds_ep[n];
+                y00 = leaky(y00 * e.x + e.y); y01 = leaky(y01 * e.x + e.y);
+                y10 = leaky(y10 * e.x + e.y); y11 = leaky(y11 * e.x + e.y);
+            }
+            const unsigned so = (unsigned)((t * 16 + r) * HW) * 4u;  // scalar
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u32, make_float2(y00, y01)), ors, (int)vo0, (int)so, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u32, make_float2(y10, y11)), ors, (int)vo1, (int)so, 0);
+            if (pool) {  // F.avg_pool2d (2, 2) of the block output (resunet.py:197), summed in the reference's row-major order
+                float sum = y00 + y01;
+                sum += y10;
+                sum += y11;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, sum * 0.25f), prs, (int)vp,
+                                                      (int)((unsigned)((t * 16 + r) * HWo) * 4u), 0);
+            }
+        }
+}
+
 template <int FLAGS, int CIN, int CIN2>
 __global__ __launch_bounds__(NTH32, 2) void wino32_kernel(ConvArgs p) {
     constexpr bool PRO = (FLAGS & F_PRO) != 0;
@@ -137,8 +204,8 @@ __global__ __launch_bounds__(NTH32, 2) void wino32_kernel(ConvArgs p) {
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kq = lane >> 4, l15 = lane & 15;
     float* wtab = lds + U_F + U2_F + wave * (TAB_F + EPI_F);  // this wave's private tables
-    float* wes = wtab + TAB_F;
-    float* weh = wes + 32;
+    float* wes = wtab + TAB_F;  // epilogue (scale, shift) pairs of the 32 output channels, current clip
+    float* weh = wes + 32;      // (shared epilogue of the MASK / plain-RES variants: separate arrays)
     const int HW = p.H * p.W;
 
     // ---- start-up: the layer's transform-domain weights -> LDS, once (linear LDS-DMA copy of the image lass_finalize
@@ -155,9 +222,14 @@ __global__ __launch_bounds__(NTH32, 2) void wino32_kernel(ConvArgs p) {
         }
     }
     if (BIAS && tid < 32) lds_bias[tid] = p.bias[tid];
+    constexpr bool OWN_EPI = !MASK && !((FLAGS & F_RES) != 0 && !RESPRE);  // w32_epilogue; else wino_epilogue.h
     if ((PRE || RESPRE) && tid < 32) {
-        lds_pw[tid] = p.pre_w[tid];
-        lds_pb[tid] = p.pre_b[tid];
+        if (OWN_EPI) {
+            *reinterpret_cast<float2*>(lds_pw + tid * 2) = make_float2(p.pre_w[tid], p.pre_b[tid]);
+        } else {
+            lds_pw[tid] = p.pre_w[tid];
+            lds_pb[tid] = p.pre_b[tid];
+        }
     }
     if (MASK && tid < 99) lds_mw[tid] = tid < 96 ? p.mask_w[tid] : p.mask_b[tid - 96];
     wait_vmcnt<0>();
@@ -199,10 +271,8 @@ __global__ __launch_bounds__(NTH32, 2) void wino32_kernel(ConvArgs p) {
                 if (PRE) t = make_float2(p.pre_w[lane] * t.x, p.pre_b[lane] * t.x + t.y);
                 *reinterpret_cast<float2*>(wtab + lane * 2) = t;
             }
-            if (EPI && lane < 32) {
-                wes[lane] = p.epi_scale[lane];
-                weh[lane] = p.epi_shift[(size_t)b * p.epi_shift_bs + lane];
-            }
+            if (EPI && lane < 32)
+                *reinterpret_cast<float2*>(wes + lane * 2) = make_float2(p.epi_scale[lane], p.epi_shift[(size_t)b * p.epi_shift_bs + lane]);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same wave writes and reads: in-order LDS, no barrier
         }
 
@@ -386,7 +456,13 @@ __global__ __launch_bounds__(NTH32, 2) void wino32_kernel(ConvArgs p) {
 #ifdef LASS_CONV_DIAG
         dg_t2 = clock64();
 #endif
-        if (!(EXPF & 2)) wino_epilogue<FLAGS>(p, acc, b, 0, 0, oy, ox, lane, lds_bias, wes, weh, lds_pw, lds_pb, lds_mw);
+        if (!(EXPF & 2)) {
+            if constexpr (OWN_EPI)
+                w32_epilogue<FLAGS>(p, acc, b, oy, ox, kq, lds_bias, reinterpret_cast<const float2*>(wes),
+                                    reinterpret_cast<const float2*>(lds_pw));
+            else
+                wino_epilogue<FLAGS>(p, acc, b, 0, 0, oy, ox, lane, lds_bias, wes, weh, lds_pw, lds_pb, lds_mw);
+        }
         };  // run_strip
         if (border)
             run_strip(std::true_type{});
@@ -481,6 +557,7 @@ hipError_t launch32(const ConvArgs& p, hipStream_t stream) {
 bool lass_wino32_supported(ConvKind kind, const ConvArgs& p) {
     static const int kind_mask = [] { const char* e = getenv("LASS_W32_KINDS"); return e ? atoi(e) : 0xff; }();  // debugging aid
     if (!((kind_mask >> (int)kind) & 1)) return false;
+    if (p.pool_out && p.pool_h != 2) return false;
     if (p.N != 32 || p.Nw != 32 || p.W < 32 || (p.W % 32) != 0 || (p.H % 2) != 0 || !p.w_wino32) return false;
     // 32-bit byte offsets inside one clip's tensors
     if ((unsigned long long)p.Cin * p.H * p.W * 4ull > 0xFFFF0000ull) return false;
