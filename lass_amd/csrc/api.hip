@@ -108,6 +108,7 @@ struct lass_ctx {
     bool fuse_preconv = true;  // LASS_FUSE_PRECONV=0 materialises pre_conv's output with its own kernel
     bool fuse_pool = true;  // LASS_FUSE_POOL=0 selects the stand-alone pool kernel (A/B + parity of both paths)
     bool fuse_catb = true;  // bf16 mode: decoder concats as blocked bf16 copies (LASS_FUSE_CATB=0: f32 concat)
+    bool fuse_block = true;  // bf16 mode: encoder_block1 as one kernel, intermediate in LDS (LASS_FUSE_BLOCK=0: two launches)
     bool fuse_mask = true;  // LASS_FUSE_MASK=0 keeps after_conv + mask as their own kernel behind decoder_block6
     // hipGraph replay of lass_separate (LASS_GRAPH=0 disables): the ~40 launches of one (pointers, shape) combination are
     // captured once on an internal stream and replayed on the caller's stream
@@ -426,7 +427,7 @@ int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int
         return fail(c, LASS_ERR_STATE, "blocked bf16 concat copies need the bf16 kernels");
     if (cat_in) p.in_bf16 = cat_in->act;
     const bool wino1 = !bf1 && c->wino && rb.u1 && lass_wino_supported(p);
-    {
+    auto launch_conv1 = [&]() -> int {
         ProfScope ps(c, st, P_CONV3X3);
         if (bf1)
             HIP_TRY(c, lass_launch_conv_bf16(x0 ? CONV1_ACT_PRE : CONV1_ACT, p, st));
@@ -436,7 +437,8 @@ int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int
             HIP_TRY(c, lass_launch_wino(x0 ? CONV1_ACT_PRE : CONV1_ACT, p, st));
         else
             HIP_TRY(c, lass_launch_conv(x0 ? CONV1_ACT_PRE : CONV1_ACT, p, st));
-    }
+        return 0;
+    };
     ConvArgs q;
     q.in = a2; q.in_bs = rb.cout * HW; q.Cin = rb.cout; q.w = rb.w2; q.Nw = rb.cout; q.N = rb.cout;
     q.out = out; q.out_bs = out_bs; q.B = B; q.H = H; q.W = W;
@@ -472,13 +474,24 @@ int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int
         q.act_scale = skip_out->scale + rb.cout; q.act_shift = skip_out->shift + rb.cout; q.act_shift_bs = c->n_shift;
     }
     const bool wino2 = !bf2 && c->wino && rb.u2 && lass_wino_supported(q);
-    ProfScope ps(c, st, P_CONV3X3);
     if (rb.cin == rb.cout) {
         q.res = x; q.res_bs = x_bs;
         if (x0) {
             q.res = x0; q.res_bs = HW;
             q.pre_w = pre->w; q.pre_b = pre->b;
         }
+    }
+    // bf16 mode, encoder_block1 in the blocked-copy pipeline: the whole block as ONE kernel, its 32-channel intermediate
+    // kept in LDS (conv_bf16_fused.hip; LASS_FUSE_BLOCK=0 restores the two launches)
+    if (bf2 && x0 && c->fuse_block && c->compute_mode == LASS_COMPUTE_BF16 && skip_out && rb.cin == rb.cout &&
+        lass_enc1_fused_bf16_supported(p, q)) {
+        ProfScope ps(c, st, P_CONV3X3);
+        HIP_TRY(c, lass_launch_enc1_fused_bf16(p, q, st));
+        return 0;
+    }
+    if (int r1 = launch_conv1()) return r1;
+    ProfScope ps(c, st, P_CONV3X3);
+    if (rb.cin == rb.cout) {
         if (bf2)
             HIP_TRY(c, lass_launch_conv_bf16(x0 ? CONV2_IDENT_PRE : CONV2_IDENT, q, st));
         else if (wino2 && c->wino32 && lass_wino32_supported(x0 ? CONV2_IDENT_PRE : CONV2_IDENT, q))
@@ -657,6 +670,7 @@ static int create_impl(lass_ctx** out, int device_id, const Geometry& geom) {
     if (const char* e = getenv("LASS_FUSE_POOL")) c->fuse_pool = atoi(e) != 0;
     if (const char* e = getenv("LASS_FUSE_MASK")) c->fuse_mask = atoi(e) != 0;
     if (const char* e = getenv("LASS_FUSE_CATB")) c->fuse_catb = atoi(e) != 0;
+    if (const char* e = getenv("LASS_FUSE_BLOCK")) c->fuse_block = atoi(e) != 0;
     if (const char* e = getenv("LASS_FUSE_PRECONV")) c->fuse_preconv = atoi(e) != 0;
     if (const char* e = getenv("LASS_GRAPH")) c->use_graph = atoi(e) != 0;
     c->prof.resize(P_COUNT);

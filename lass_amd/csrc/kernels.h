@@ -113,6 +113,11 @@ hipError_t lass_launch_conv_bf16(ConvKind kind, const ConvArgs& p, hipStream_t s
 hipError_t lass_launch_weights_bf16(const float* w, int Cout, int Cin, int taps, void* dst, int lo, int transposed,
                                     hipStream_t stream);
 
+// ---- conv_bf16_fused.hip (bf16 mode: encoder_block1's ConvBlockRes as one kernel, intermediate in LDS) -------------------
+// p = the block's CONV1_ACT_PRE arguments, q = its CONV2_IDENT_PRE arguments with blocked bf16 outputs
+bool lass_enc1_fused_bf16_supported(const ConvArgs& p, const ConvArgs& q);
+hipError_t lass_launch_enc1_fused_bf16(const ConvArgs& p, const ConvArgs& q, hipStream_t stream);
+
 // ---- stft.hip -----------------------------------------------------------------------------------------------------
 // Multi-resolution analysis (scripts/precompute_stfts.py:19-58,573-590): nwin centred STFTs (n_fft = win in {256, 512,
 // 1024, 2048}, periodic Hann, reflect pad, common hop) of the same waveforms in one launch, torchlibrosa-magphase
