@@ -1,14 +1,19 @@
 #!/usr/bin/env python3
-"""Per-layer MFMA utilisation from a rocprofv3 --pmc pass over tools/conv_bench.py (one iteration, B=16, T=1024):
+"""Per-launch MFMA utilisation of the SHIPPED pipeline from a rocprofv3 --pmc pass over
+`bench.py --steps 1 --warmup 1 --dtype D --modes none` (B=16, 10 s clips): the conv / transposed-conv launches of the LAST
+step (everything behind the last stft2_kernel dispatch), in launch order = lass_separate's order (api.hip separate_impl):
     mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs)          (MI355X_MICROARCH.md: the SQ
 counter counts cycles per SIMD summed over the chip, GRBM_GUI_ACTIVE is summed over the 8 XCDs)
-and the rates each conv launch sustained.  Usage: pmc_table.py counter_collection.csv [f32|bf16] > table.md"""
+and the rates each launch sustained.  Usage: pmc_table.py counter_collection.csv [f32|bf16|bf16x3] > table.md"""
 import collections
 import csv
+import re
 import sys
 
 sys.path.insert(0, '.')
 from lass_amd import arch
+
+CONV = re.compile(r'wino32_kernel|wino_kernel|conv_kernel|conv_bf16_kernel|enc1_fused_bf16_kernel')
 
 
 def load(path):
@@ -17,43 +22,46 @@ def load(path):
         k = int(r['Dispatch_Id'])
         e = d.setdefault(k, {'name': r['Kernel_Name'], 't0': int(r['Start_Timestamp']), 't1': int(r['End_Timestamp'])})
         e[r['Counter_Name']] = e.get(r['Counter_Name'], 0.0) + float(r['Counter_Value'])
-    return d
+    return list(d.values())
+
+
+def last_step(disp):
+    last = max(i for i, v in enumerate(disp) if 'stft2_kernel' in v['name'] and 'istft2' not in v['name'])
+    return [v for v in disp[last:] if CONV.search(v['name']) and 'relayout' not in v['name'] and 'weights' not in v['name']]
+
+
+def launch_sequence(convs):
+    """(name, 3x3 macs, shortcut macs, kind, h) per launch, following the dispatches (a fused block is one launch)."""
+    rows = arch.conv_layer_table(1024)
+    by = {r['name']: r for r in rows}
+    blocks = [e.name for e in arch.ENCODERS] + [d.name for d in arch.DECODERS]
+    seq, it = [], iter(convs)
+    for blk in blocks:
+        if blk + '.up' in by:
+            seq.append((blk + '.up', by[blk + '.up']['macs'], 0, 'tconv', by[blk + '.up']['h'], next(it)))
+        c1, c2 = by[blk + '.conv1'], by[blk + '.conv2']
+        sc = by[blk + '.shortcut']['macs'] if blk + '.shortcut' in by else 0
+        v = next(it)
+        if 'fused' in v['name']:
+            seq.append((blk + ' (conv1+conv2, one kernel)', c1['macs'] + c2['macs'], sc, '3x3', c1['h'], v))
+        else:
+            seq.append((blk + '.conv1', c1['macs'], 0, '3x3', c1['h'], v))
+            seq.append((blk + '.conv2' + ('+sc' if sc else ''), c2['macs'], sc, '3x3', c2['h'], next(it)))
+    rest = list(it)
+    assert not rest, ('unmatched launches', len(rest))
+    return seq
 
 
 if __name__ == '__main__':
-    d = load(sys.argv[1])
     mode = sys.argv[2] if len(sys.argv) > 2 else 'f32'
-    convs = [v for v in d.values() if ('conv_kernel' in v['name'] or 'wino_kernel' in v['name'] or 'conv_bf16_kernel' in v['name'])
-             and 'relayout' not in v['name']]
-    # shortcut rows of arch.conv_layer_table come AFTER conv2: attach them
-    rows = arch.conv_layer_table(1024)
-    seq = []
-    for i, r in enumerate(rows):
-        if r['kind'] == '3x3':
-            sc = 0
-            for j in (i + 1, i + 2):
-                if j < len(rows) and rows[j]['name'].endswith('.shortcut') and r['name'].endswith('.conv2') and \
-                        rows[j]['name'].rsplit('.', 1)[0] == r['name'].rsplit('.', 1)[0]:
-                    sc = rows[j]['macs']
-            seq.append((r['name'] + ('+sc' if sc else ''), r['macs'], sc, r['kind'], r['h']))
-        elif r['kind'] == 'tconv':
-            seq.append((r['name'], r['macs'], 0, 'tconv', r['h']))
-    # conv_bench runs every job (block = conv1 + conv2, .up = one launch) once as warm-up and once timed (--iters 1):
-    # 2 x k consecutive dispatches per job, of which the last k are kept
-    kept, pos, i = [], 0, 0
-    while i < len(seq):
-        k = 1 if seq[i][3] == 'tconv' else 2
-        kept += convs[pos + k:pos + 2 * k]
-        pos += 2 * k
-        i += k
-    assert pos == len(convs), (pos, len(convs))
-    convs = kept
+    seq = launch_sequence(last_step(load(sys.argv[1])))
     B = 16
     peak = 157.3 if mode == 'f32' else 2500.0
-    print(f'| launch | ms | algorithmic TFLOP/s | executed TFLOP/s | executed / {peak:g} peak | MFMA busy (SQ_VALU_MFMA_BUSY_CYCLES) | clock GHz |')
-    print('|---|---|---|---|---|---|---|')
+    print(f'| launch | kernel | ms | algorithmic TFLOP/s | executed TFLOP/s | executed / {peak:g} peak | MFMA busy (SQ_VALU_MFMA_BUSY_CYCLES) | clock GHz |')
+    print('|---|---|---|---|---|---|---|---|')
     tot_ms = tot_alg = tot_exe = 0.0
-    for (name, macs, sc, kind, h), v in zip(seq, convs):
+    cls = {'3x3': 0.0, 'tconv': 0.0}
+    for name, macs, sc, kind, h, v in seq:
         dt = (v['t1'] - v['t0']) / 1e9
         alg = 2.0 * B * (macs + sc)
         wino = mode == 'f32' and kind == '3x3' and h % 2 == 0 and 'wino' in v['name']
@@ -61,6 +69,8 @@ if __name__ == '__main__':
         gui = v.get('GRBM_GUI_ACTIVE', 0.0) / 8.0
         busy = v.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / (gui * 1024.0) if gui else float('nan')
         clk = gui / dt / 1e9 if dt > 0 else float('nan')
-        tot_ms += dt * 1e3; tot_alg += alg; tot_exe += exe
-        print(f'| {name} | {dt*1e3:.3f} | {alg/dt/1e12:.1f} | {exe/dt/1e12:.1f} | {exe/dt/1e12/peak:.3f} | {busy:.3f} | {clk:.2f} |')
-    print(f'| **all {len(seq)} launches** | {tot_ms:.3f} | {tot_alg/tot_ms/1e9:.1f} | {tot_exe/tot_ms/1e9:.1f} | {tot_exe/tot_ms/1e9/peak:.3f} | | |')
+        tot_ms += dt * 1e3; tot_alg += alg; tot_exe += exe; cls[kind] += dt * 1e3
+        kn = re.sub(r'.*::', '', v['name'].split('(')[0])
+        print(f'| {name} | `{kn}` | {dt*1e3:.3f} | {alg/dt/1e12:.1f} | {exe/dt/1e12:.1f} | {exe/dt/1e12/peak:.3f} | {busy:.3f} | {clk:.2f} |')
+    print(f'| **all {len(seq)} launches** | | {tot_ms:.3f} | {tot_alg/tot_ms/1e9:.1f} | {tot_exe/tot_ms/1e9:.1f} | {tot_exe/tot_ms/1e9/peak:.3f} | | |')
+    print(f'\nconv3x3 class {cls["3x3"]:.3f} ms, transposed convs {cls["tconv"]:.3f} ms (under the counters; bench.py\'s `conv_ms` is the un-profiled figure)')

@@ -3,7 +3,9 @@
 #  1. rocprofv3 --kernel-trace --stats of the default bench (f32 headline + bf16 / bf16x3 modes in one run)
 #  2. separate --pmc passes (FETCH_SIZE, WRITE_SIZE) of `bench.py --steps 1 --warmup 1` for f32 and bf16
 #  3. FETCH_SIZE / WRITE_SIZE calibration of the access shapes the kernels use (tools/fetch_calib.hip)
-#  4. SQ counters per conv launch (tools/conv_bench.py, one iteration) for f32 and bf16 -> per-layer MFMA utilisation
+#  4. SQ counters per conv launch of the pipeline itself (bench.py --steps 1, last step) for f32 and bf16 -> per-launch MFMA
+#     utilisation
+#  5. the evaluator end to end on 256 clips (tools/eval_bench.py) and the long-form cases (tools/longform_bench.py)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_round
@@ -16,8 +18,8 @@ done
 hipcc -O3 --offload-arch=gfx950 $R/tools/fetch_calib.hip -o $O/fetch_calib 2>/dev/null || exit 1
 timeout -k 10 120 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/calib_fetch -o x -- $O/fetch_calib > $O/calib_fetch.log 2>&1 || exit 1
 timeout -k 10 120 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/calib_write -o x -- $O/fetch_calib > $O/calib_write.log 2>&1 || exit 1
-for D in f32 bf16; do
-  LASS_COMPUTE=$D timeout -k 10 150 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d $O/pmc_sq_$D -o x -- python3 $R/tools/conv_bench.py --iters 1 > $O/pmc_sq_$D.log 2>&1 || exit 1
+for D in f32 bf16; do  # the SHIPPED pipeline, launch by launch (not the stage API)
+  timeout -k 10 150 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d $O/pmc_sq_$D -o x -- python3 $R/bench.py --steps 1 --warmup 1 --dtype $D --modes none --no-cpu-baseline > $O/pmc_sq_$D.log 2>&1 || exit 1
 done
 cd $R
 F=$(find $O/calib_fetch -name '*counter_collection.csv'); W=$(find $O/calib_write -name '*counter_collection.csv')
@@ -28,4 +30,6 @@ for D in f32 bf16; do
   cat $O/mfma_util_$D.md
 done
 cp $(find $O/stats -name '*kernel_stats.csv') $O/kernel_stats.csv
+timeout -k 10 200 python3 tools/eval_bench.py 260 > $O/eval_bench_260clips.log 2>&1
+timeout -k 10 200 python3 tools/longform_bench.py > $O/longform_bench.log 2>&1
 echo done

@@ -28,14 +28,20 @@ def per_dispatch(path, counter):
 
 
 def is_conv3x3(name):
-    if 'wino_kernel' in name:
+    if 'wino_kernel' in name or 'wino32_kernel' in name or 'enc1_fused_bf16_kernel' in name:
         return True
     if 'conv_bf16_kernel<9' in name or 'conv_bf16_kernelILi9E' in name:
         return True
     return ('conv_kernel' in name) and 'relayout' not in name and ('<9,' in name or 'ILi9E' in name)
 
 
-def main(fetch_csv, write_csv, out_json, dtype, calib_json=None, launches_per_step=26):
+def last_step(entries):
+    """The dispatches behind the last stft2_kernel (the last step of the run)."""
+    last = max(i for i, e in enumerate(entries) if 'stft2_kernel' in e['name'] and 'istft2' not in e['name'])
+    return entries[last:]
+
+
+def main(fetch_csv, write_csv, out_json, dtype, calib_json=None):
     ratio_f, ratio_w = 0.5, 1.0
     calib = None
     if calib_json:
@@ -44,9 +50,10 @@ def main(fetch_csv, write_csv, out_json, dtype, calib_json=None, launches_per_st
         rw = list(calib['write_ratio'].values())
         assert max(rf) - min(rf) < 1e-3 and max(rw) - min(rw) < 1e-3, "access shapes disagree: per-kernel factors needed"
         ratio_f, ratio_w = sum(rf) / len(rf), sum(rw) / len(rw)
-    f = [e for e in per_dispatch(fetch_csv, 'FETCH_SIZE') if is_conv3x3(e['name'])][-launches_per_step:]
-    w = [e for e in per_dispatch(write_csv, 'WRITE_SIZE') if is_conv3x3(e['name'])][-launches_per_step:]
-    assert len(f) == launches_per_step and len(w) == launches_per_step, (len(f), len(w))
+    f = [e for e in last_step(per_dispatch(fetch_csv, 'FETCH_SIZE')) if is_conv3x3(e['name'])]
+    w = [e for e in last_step(per_dispatch(write_csv, 'WRITE_SIZE')) if is_conv3x3(e['name'])]
+    launches_per_step = len(f)  # 26 (f32, bf16x3) or 25 (bf16: encoder_block1 is one kernel)
+    assert launches_per_step in (25, 26) and len(w) == launches_per_step, (len(f), len(w))
     fetch = sum(e['v'] for e in f) * 1024.0 / ratio_f
     write = sum(e['v'] for e in w) * 1024.0 / ratio_w
     res = {
