@@ -246,7 +246,7 @@ __global__ __launch_bounds__(NTH32, 2) void wino32_kernel(ConvArgs p) {
 #ifdef LASS_CONV_DIAG
     // timing experiments, compile-time (-DW32_EXP=n; results are wrong when set; a run-time switch would put a branch around
     // every MFMA and wreck the schedule being measured): 1 no patch loads, 2 no epilogue, 8 no MFMA, 16 no patch transform,
-    // 32 one wave per SIMD
+    // 32 one wave per SIMD, 64 patch loads of every k-step from channel group 0 (same instructions, cache hits)
     constexpr int EXPF = W32_EXP;
     long long dg[4] = {0, 0, 0, 0};
     const long long dg_k0 = clock64(), dg_r0 = wall_clock64();
@@ -255,7 +255,18 @@ __global__ __launch_bounds__(NTH32, 2) void wino32_kernel(ConvArgs p) {
     constexpr int EXPF = 0;
 #endif
 
-    for (unsigned blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    // Block order: workgroup g runs on XCD g % 8 (round-robin dispatch), and every XCD has its own L2.  Each XCD walks ONE
+    // contiguous range of blocks, its workgroups side by side in it: the strips that share halo rows / the 128-byte lines
+    // either side of a strip run at the same time under the same L2 (in plain round-robin order horizontal neighbours sit
+    // on 8 different XCDs and every one of them fetches the shared lines from HBM: 5x the algorithmic read, measured).
+    unsigned blk = blockIdx.x, blk_end = nblk, blk_step = gridDim.x;
+    if ((gridDim.x & 7u) == 0 && nblk >= gridDim.x) {
+        const unsigned chunk = (nblk + 7u) >> 3;
+        blk = (blockIdx.x & 7u) * chunk + (blockIdx.x >> 3);
+        blk_end = min(nblk, ((blockIdx.x & 7u) + 1u) * chunk);
+        blk_step = gridDim.x >> 3;
+    }
+    for (; blk < blk_end; blk += blk_step) {
         const int b = (int)(blk / blocks_per_clip);
         const unsigned rr = blk - (unsigned)b * blocks_per_clip;
         const int by = (int)(rr / (unsigned)tiles_x), bx = (int)(rr - (unsigned)by * (unsigned)tiles_x);
@@ -307,7 +318,7 @@ __global__ __launch_bounds__(NTH32, 2) void wino32_kernel(ConvArgs p) {
         float2 tab;              // (scale, shift) of this lane's channel of the k-step being prepared
 
         auto pload = [&](int ks, f2u (&buf)[8]) __attribute__((always_inline)) {
-            const unsigned soff = PRE ? 0u : (unsigned)(ks * 4 * HW) * 4u;
+            const unsigned soff = (PRE || (EXPF & 64)) ? 0u : (unsigned)(ks * 4 * HW) * 4u;  // 64: every k-step re-reads channel group 0 (cache hits)
             if (EXPF & 1) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) buf[i] = f2u{0.25f, 0.5f};
