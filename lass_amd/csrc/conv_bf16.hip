@@ -631,8 +631,8 @@ hipError_t launch_bf16_one(const ConvArgs& p0, hipStream_t stream) {
     constexpr int PHT = 4 * NPX * (32 / PW);
     p.gx = (p.W / PW) * ((p.H + PHT - 1) / PHT);
     p.gy = p.N / (32 * NCO);
-    static const bool xcd = [] { const char* e = getenv("LASS_XCD_MAP"); return !e || atoi(e) != 0; }();
-    p.xcd_map = (xcd && p.gy > 1 && ((long)p.gx * p.B) % 8 == 0) ? 1 : 0;
+    static const int xcd = [] { const char* e = getenv("LASS_XCD_MAP"); return e ? atoi(e) : 2; }();  // 0 off, 1 tile by tile, 2 contiguous ranges
+    p.xcd_map = (xcd && ((long)p.gx * p.B) % 8 == 0 && (p.gy > 1 || xcd == 2)) ? xcd : 0;
     dim3 grid((unsigned)((long)p.gx * p.gy * p.B));
     if constexpr ((FLAGS & F_NOSPLIT) != 0) {
         if (p.w_bf16_lo) return hipErrorInvalidValue;

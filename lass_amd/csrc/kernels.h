@@ -86,7 +86,8 @@ struct ConvArgs {
     int pool_h = 2;              // vertical pool factor (1 or 2); horizontal is 2
     // XCD-aware block order (wino.hip, conv_bf16.hip): launched as a 1-D grid of gx * gy * B workgroups; set by the launcher
     int gx = 0, gy = 0;        // spatial tiles per clip, cout blocks
-    int xcd_map = 0;           // 1: the gy cout blocks of one (tile, clip) run on ONE XCD (they re-read the same input tile)
+    int xcd_map = 0;           // 1, 2: the gy cout blocks of one (tile, clip) run on ONE XCD (they re-read the same input tile);
+                               // 2: and every XCD walks one contiguous range of tiles (block_coords, wino_common.h)
     long long* dbg = nullptr;  // diagnostic builds (-DLASS_CONV_DIAG) only: 8 int64 per block
     int exp = 0;  // diagnostic builds only: timing-experiment switches (env LASS_EXP, see wino.hip)
 };

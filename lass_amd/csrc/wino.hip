@@ -621,10 +621,10 @@ hipError_t launch_wino_v(const ConvArgs& p0, hipStream_t stream) {
     p.exp = exp_flags;
 #endif
     const bool wide = p.N % 64 == 0;  // 32-cout blocks on the >= 64-cout layers: measured 10 % slower (V work doubles)
-    static const bool xcd = [] { const char* e = getenv("LASS_XCD_MAP"); return !e || atoi(e) != 0; }();
+    static const int xcd = [] { const char* e = getenv("LASS_XCD_MAP"); return e ? atoi(e) : 2; }();  // 0 off, 1 tile by tile, 2 contiguous ranges
     auto set_grid = [&](int gx, int gy) {  // 1-D grid, decoded by block_coords()
         p.gx = gx; p.gy = gy;
-        p.xcd_map = (xcd && gy > 1 && ((long)gx * p.B) % 8 == 0) ? 1 : 0;
+        p.xcd_map = (xcd && ((long)gx * p.B) % 8 == 0 && (gy > 1 || xcd == 2)) ? xcd : 0;
         return dim3((unsigned)((long)gx * gy * p.B));
     };
     if (p.W < 32) {  // 16- / 8-bin layers: 64-cout blocks of 8 x 16 or 16 x 8 output pixels

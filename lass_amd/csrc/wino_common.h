@@ -28,7 +28,9 @@ __device__ __forceinline__ void block_coords(const ConvArgs& p, int& bx, int& by
         const unsigned q = lin & 7u, s = lin >> 3;
         const unsigned g = s / (unsigned)p.gy;
         y = s - g * (unsigned)p.gy;
-        xz = g * 8u + q;
+        // XCD q walks ONE contiguous range of tiles (neighbouring tiles share halo rows and 128-byte lines: under one L2
+        // they are fetched once; dealt out tile by tile, xz = g * 8 + q, every XCD fetched them for itself)
+        xz = p.xcd_map == 2 ? q * (((unsigned)p.gx * (unsigned)p.B) >> 3) + g : g * 8u + q;
     } else {
         xz = lin / (unsigned)p.gy;
         y = lin - xz * (unsigned)p.gy;
