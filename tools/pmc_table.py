@@ -70,7 +70,7 @@ if __name__ == '__main__':
         busy = v.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / (gui * 1024.0) if gui else float('nan')
         clk = gui / dt / 1e9 if dt > 0 else float('nan')
         tot_ms += dt * 1e3; tot_alg += alg; tot_exe += exe; cls[kind] += dt * 1e3
-        kn = re.sub(r'.*::', '', v['name'].split('(')[0])
+        kn = re.sub(r'\(anonymous namespace\)::|^void ', '', v['name']).split('(')[0]
         print(f'| {name} | `{kn}` | {dt*1e3:.3f} | {alg/dt/1e12:.1f} | {exe/dt/1e12:.1f} | {exe/dt/1e12/peak:.3f} | {busy:.3f} | {clk:.2f} |')
     print(f'| **all {len(seq)} launches** | | {tot_ms:.3f} | {tot_alg/tot_ms/1e9:.1f} | {tot_exe/tot_ms/1e9:.1f} | {tot_exe/tot_ms/1e9/peak:.3f} | | |')
     print(f'\nconv3x3 class {cls["3x3"]:.3f} ms, transposed convs {cls["tconv"]:.3f} ms (under the counters; bench.py\'s `conv_ms` is the un-profiled figure)')

@@ -9,7 +9,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_round
-mkdir -p $O
+rm -rf $O; mkdir -p $O
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o x -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats.log || exit 1
 for D in f32 bf16; do
   timeout -k 10 150 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_$D -o x -- python3 $R/bench.py --steps 1 --warmup 1 --dtype $D --modes none --no-cpu-baseline > $O/pmc_fetch_$D.json 2> $O/pmc_fetch_$D.log || exit 1
@@ -28,6 +28,7 @@ for D in f32 bf16; do
   python3 tools/traffic_summary.py $(find $O/pmc_fetch_$D -name '*counter_collection.csv') $(find $O/pmc_write_$D -name '*counter_collection.csv') $O/conv_traffic_$D.json $D $O/fetch_calibration.json
   python3 tools/pmc_table.py $(find $O/pmc_sq_$D -name '*counter_collection.csv') $D > $O/mfma_util_$D.md
   cat $O/mfma_util_$D.md
+  python3 tools/traffic_table.py $(find $O/pmc_fetch_$D -name '*counter_collection.csv') $(find $O/pmc_write_$D -name '*counter_collection.csv') $D > $O/traffic_per_launch_$D.md
 done
 cp $(find $O/stats -name '*kernel_stats.csv') $O/kernel_stats.csv
 timeout -k 10 200 python3 tools/eval_bench.py 260 > $O/eval_bench_260clips.log 2>&1
