@@ -84,7 +84,7 @@ class _Stager:
 
 class DCASEEvaluator:
     def __init__(self, sampling_rate=16000, eval_indexes="lass_synthetic_validation.csv", audio_dir="lass_validation",
-                 batch_size: int = 16, device_mixing: bool = True, io_workers: int = 4) -> None:
+                 batch_size: int = 16, device_mixing: bool = True, io_workers: int = 2) -> None:
         r"""DCASE T9 LASS evaluator (dcase_evaluator.py:28-47)."""
         self.sampling_rate = sampling_rate
         with open(eval_indexes) as csv_file:
