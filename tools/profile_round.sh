@@ -11,6 +11,9 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_round
 rm -rf $O; mkdir -p $O
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o x -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats.log || exit 1
+# f32 alone (the headline's kernels by name, no mode legs mixed in): rocprof average per launch vs the in-bench HIP events
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_f32only -o x -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --modes none > $O/bench_f32only_under_rocprof.json 2> $O/stats_f32only.log || exit 1
+cp $(find $O/stats_f32only -name '*kernel_stats.csv') $O/kernel_stats_f32only.csv
 for D in f32 bf16; do
   timeout -k 10 150 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_$D -o x -- python3 $R/bench.py --steps 1 --warmup 1 --dtype $D --modes none --no-cpu-baseline > $O/pmc_fetch_$D.json 2> $O/pmc_fetch_$D.log || exit 1
   timeout -k 10 150 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_$D -o x -- python3 $R/bench.py --steps 1 --warmup 1 --dtype $D --modes none --no-cpu-baseline > $O/pmc_write_$D.json 2> $O/pmc_write_$D.log || exit 1
@@ -31,6 +34,6 @@ for D in f32 bf16; do
   python3 tools/traffic_table.py $(find $O/pmc_fetch_$D -name '*counter_collection.csv') $(find $O/pmc_write_$D -name '*counter_collection.csv') $D > $O/traffic_per_launch_$D.md
 done
 cp $(find $O/stats -name '*kernel_stats.csv') $O/kernel_stats.csv
-timeout -k 10 200 python3 tools/eval_bench.py 260 > $O/eval_bench_260clips.log 2>&1
+EVAL_BENCH_REPS=5 timeout -k 10 200 python3 tools/eval_bench.py 260 > $O/eval_bench_260clips.log 2>&1
 timeout -k 10 200 python3 tools/longform_bench.py > $O/longform_bench.log 2>&1
 echo done
