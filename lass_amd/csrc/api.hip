@@ -852,10 +852,12 @@ int lass_finalize(lass_ctx* c, int compute_mode) {
                 return LASS_ERR_HIP;
             HIP_TRY(c, lass_launch_wino_weights(w1, rb.cout, rb.cin, rb.u1, st));
             HIP_TRY(c, lass_launch_wino_weights(w2, rb.cout, rb.cout, rb.u2, st));
-            if (rb.cout == 32 && rb.cin % 8 == 0) {  // full-resolution 32-channel blocks: wino32.hip
-                if (dev_alloc(c, &rb.u1r, (size_t)512 * rb.cin) || dev_alloc(c, &rb.u2r, (size_t)512 * rb.cout)) return LASS_ERR_HIP;
-                HIP_TRY(c, lass_launch_wino32_weights(w1, rb.cin, rb.u1r, st));
-                HIP_TRY(c, lass_launch_wino32_weights(w2, rb.cout, rb.u2r, st));
+            // full-resolution 32-channel blocks, and encoder_block2 (32 -> 64) as two 32-cout slices: wino32.hip
+            if ((rb.cout == 32 && rb.cin % 8 == 0) || (rb.cout == 64 && rb.cin == 32)) {
+                const size_t ns = rb.cout / 32;
+                if (dev_alloc(c, &rb.u1r, ns * 512 * rb.cin) || dev_alloc(c, &rb.u2r, ns * 512 * rb.cout)) return LASS_ERR_HIP;
+                HIP_TRY(c, lass_launch_wino32_weights(w1, rb.cout, rb.cin, rb.u1r, st));
+                HIP_TRY(c, lass_launch_wino32_weights(w2, rb.cout, rb.cout, rb.u2r, st));
             }
         }
         rb.wsc = nullptr;
@@ -881,9 +883,9 @@ int lass_finalize(lass_ctx* c, int compute_mode) {
             if (c->wino && c->compute_mode == LASS_COMPUTE_F32) {
                 if (dev_alloc(c, &rb.usc, (size_t)4 * rb.cout * rb.cin)) return LASS_ERR_HIP;
                 HIP_TRY(c, lass_launch_wino_shortcut_weights(ws, rb.cout, rb.cin, rb.usc, st));
-                if (rb.cout == 32 && rb.cin % 8 == 0) {
-                    if (dev_alloc(c, &rb.uscr, (size_t)128 * rb.cin)) return LASS_ERR_HIP;
-                    HIP_TRY(c, lass_launch_wino32_shortcut_weights(ws, rb.cin, rb.uscr, st));
+                if ((rb.cout == 32 && rb.cin % 8 == 0) || (rb.cout == 64 && rb.cin == 32)) {
+                    if (dev_alloc(c, &rb.uscr, (size_t)(rb.cout / 32) * 128 * rb.cin)) return LASS_ERR_HIP;
+                    HIP_TRY(c, lass_launch_wino32_shortcut_weights(ws, rb.cout, rb.cin, rb.uscr, st));
                 }
             }
         }

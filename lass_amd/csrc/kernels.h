@@ -105,8 +105,8 @@ hipError_t lass_launch_wino_shortcut_weights(const float* w, int Cout, int Cin, 
 // ---- wino32.hip (the 32-cout full-resolution layers: weights resident in LDS, persistent, waves decoupled) ------------
 bool lass_wino32_supported(ConvKind kind, const ConvArgs& p);
 hipError_t lass_launch_wino32(ConvKind kind, const ConvArgs& p, hipStream_t stream);
-hipError_t lass_launch_wino32_weights(const float* w, int Cin, float* U, hipStream_t stream);            // w (32, Cin, 3, 3)
-hipError_t lass_launch_wino32_shortcut_weights(const float* w, int Cin, float* U, hipStream_t stream);   // w (32, Cin, 1, 1)
+hipError_t lass_launch_wino32_weights(const float* w, int Cout, int Cin, float* U, hipStream_t stream);            // w (Cout, Cin, 3, 3), Cout % 32 == 0: one image per 32-cout slice
+hipError_t lass_launch_wino32_shortcut_weights(const float* w, int Cout, int Cin, float* U, hipStream_t stream);   // w (Cout, Cin, 1, 1)
 
 // ---- conv_bf16.hip (bf16-MFMA variant of the 3x3 kinds; W multiple of 32, Cin multiple of 16) ----------------------
 bool lass_bf16_supported(const ConvArgs& p);

@@ -116,16 +116,17 @@ typedef unsigned v2u32 __attribute__((ext_vector_type(2)));
 // is one 8-byte store (16 lanes = one 128-byte line).  Tables: (bias | epilogue scale, shift | pre_conv w, b) of channel n
 // at tb[n] / tb2[n] as float2.  H is even, so both rows of a tile are inside the image together.
 template <int FLAGS>
-__device__ __forceinline__ void w32_epilogue(const ConvArgs& p, f32x4 (&acc)[16][2], int b, int oy, int ox, int kq,
+__device__ __forceinline__ void w32_epilogue(const ConvArgs& p, f32x4 (&acc)[16][2], int b, int n0, int oy, int ox, int kq,
                                              const float* lds_bias, const float2* lds_ep, const float2* lds_pre) {
     constexpr bool EPI = (FLAGS & F_EPIACT) != 0, BIAS = (FLAGS & F_BIAS) != 0, RESPRE = (FLAGS & F_RESPRE) != 0;
     const int HW = p.H * p.W;
-    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)b * p.out_bs, 0, (int)(32u * (unsigned)HW * 4u), 0x00020000);
+    // n0: first output channel of this workgroup's 32-cout slice (tables in LDS are the slice's own)
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)b * p.out_bs + (size_t)n0 * HW, 0, (int)(32u * (unsigned)HW * 4u), 0x00020000);
     const unsigned vo0 = (unsigned)(kq * 4 * HW + oy * p.W + ox) * 4u, vo1 = vo0 + (unsigned)p.W * 4u;
     const bool pool = p.pool_out != nullptr;  // wave-uniform
     const int Wo = p.W / 2, HWo = (p.H / 2) * Wo;
-    const size_t pool_bs = p.pool_bs ? (size_t)p.pool_bs : (size_t)32 * HWo;
-    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(pool ? p.pool_out + (size_t)b * pool_bs : p.out, 0,
+    const size_t pool_bs = p.pool_bs ? (size_t)p.pool_bs : (size_t)p.N * HWo;
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(pool ? p.pool_out + (size_t)b * pool_bs + (size_t)n0 * HWo : p.out, 0,
                                                                           pool ? (int)(32u * (unsigned)HWo * 4u) : 0, 0x00020000);
     const unsigned vp = (unsigned)(kq * 4 * HWo + (oy >> 1) * Wo + (ox >> 1)) * 4u;
     float2 x0r0 = make_float2(0.f, 0.f), x0r1 = x0r0;
@@ -208,20 +209,48 @@ __global__ __launch_bounds__(NTH32, 2) void wino32_kernel(ConvArgs p) {
     float* weh = wes + 32;      // (shared epilogue of the MASK / plain-RES variants: separate arrays)
     const int HW = p.H * p.W;
 
-    // ---- start-up: the layer's transform-domain weights -> LDS, once (linear LDS-DMA copy of the image lass_finalize
+    // ---- which blocks, which 32-cout slice -----------------------------------------------------------------------------
+    // A block = 8 vertically adjacent strips of 2 rows x 32 columns.  A layer with N = 64 output channels runs as two
+    // slices of 32: a workgroup serves ONE slice (its weights stay resident) and walks the blocks; the workgroups of the
+    // two slices walk the same blocks side by side (the patch is transformed once per slice: that is this kernel's price).
+    // Block order: workgroup g runs on XCD g % 8 (round-robin dispatch), and every XCD has its own L2.  Each XCD walks ONE
+    // contiguous range of blocks, its workgroups side by side in it: the strips that share halo rows / the 128-byte lines
+    // either side of a strip run at the same time under the same L2 (in plain round-robin order horizontal neighbours sit
+    // on 8 different XCDs and every one of them fetches the shared lines from HBM: 5x the algorithmic read, measured).
+    const int tiles_x = p.W / 32;
+    const int rows_blk = (p.H / 2 + NW32 - 1) / NW32;
+    const unsigned blocks_per_clip = (unsigned)(tiles_x * rows_blk);
+    const unsigned nblk = blocks_per_clip * (unsigned)p.B;
+    const unsigned ns = (unsigned)p.N >> 5;  // slices; the host makes gridDim.x a multiple of it
+    unsigned blk, blk_end, blk_step, slice;
+    if ((gridDim.x & 7u) == 0 && ((gridDim.x >> 3) % ns) == 0 && nblk * ns >= gridDim.x) {
+        const unsigned j = blockIdx.x >> 3, chunk = (nblk + 7u) >> 3;
+        slice = j % ns;
+        blk = (blockIdx.x & 7u) * chunk + j / ns;
+        blk_end = min(nblk, ((blockIdx.x & 7u) + 1u) * chunk);
+        blk_step = (gridDim.x >> 3) / ns;
+    } else {
+        slice = blockIdx.x % ns;
+        blk = blockIdx.x / ns;
+        blk_end = nblk;
+        blk_step = gridDim.x / ns;
+    }
+    const int n0 = (int)slice * 32;
+
+    // ---- start-up: the slice's transform-domain weights -> LDS, once (linear LDS-DMA copy of the image lass_finalize
     // wrote, see wino32_weights_kernel), and the clip-independent tables --------------------------------------------------
     {
         const unsigned lu_addr = (unsigned)(size_t)(__attribute__((address_space(3))) float*)lu;
-        const v4i32 urs = make_rsrc_words(p.w_wino32, (unsigned)U_F * 4u);
+        const v4i32 urs = make_rsrc_words(p.w_wino32 + (size_t)slice * U_F, (unsigned)U_F * 4u);
         for (int piece = wave; piece < U_F / 256; piece += NW32)
             lds_dma_16B(urs, (unsigned)lane * 16u, (unsigned)piece * 1024u, lu_addr + (unsigned)piece * 1024u);
         if (HASB) {
-            const v4i32 u2rs = make_rsrc_words(p.w2_wino32, (unsigned)U2_F * 4u);
+            const v4i32 u2rs = make_rsrc_words(p.w2_wino32 + (size_t)slice * U2_F, (unsigned)U2_F * 4u);
             for (int piece = wave; piece < U2_F / 256; piece += NW32)
                 lds_dma_16B(u2rs, (unsigned)lane * 16u, (unsigned)piece * 1024u, lu_addr + (unsigned)(U_F * 4 + piece * 1024));
         }
     }
-    if (BIAS && tid < 32) lds_bias[tid] = p.bias[tid];
+    if (BIAS && tid < 32) lds_bias[tid] = p.bias[n0 + tid];
     constexpr bool OWN_EPI = !MASK && !((FLAGS & F_RES) != 0 && !RESPRE);  // w32_epilogue; else wino_epilogue.h
     if ((PRE || RESPRE) && tid < 32) {
         if (OWN_EPI) {
@@ -238,10 +267,6 @@ __global__ __launch_bounds__(NTH32, 2) void wino32_kernel(ConvArgs p) {
     lds_cfloat* afrag = (lds_cfloat*)lu + kq * 64 + l15 * 4;    // + ks * 2048 + pair * 256
     lds_cfloat* afrag2 = (lds_cfloat*)lu2 + kq * 64 + l15 * 4;  // + ks * 512 + pair * 256
 
-    const int tiles_x = p.W / 32;
-    const int rows_blk = (p.H / 2 + NW32 - 1) / NW32;  // a block = 8 vertically adjacent strips of 2 rows x 32 columns
-    const unsigned blocks_per_clip = (unsigned)(tiles_x * rows_blk);
-    const unsigned nblk = blocks_per_clip * (unsigned)p.B;
     int cur_b = -1;
 #ifdef LASS_CONV_DIAG
     // timing experiments, compile-time (-DW32_EXP=n; results are wrong when set; a run-time switch would put a branch around
@@ -255,17 +280,6 @@ __global__ __launch_bounds__(NTH32, 2) void wino32_kernel(ConvArgs p) {
     constexpr int EXPF = 0;
 #endif
 
-    // Block order: workgroup g runs on XCD g % 8 (round-robin dispatch), and every XCD has its own L2.  Each XCD walks ONE
-    // contiguous range of blocks, its workgroups side by side in it: the strips that share halo rows / the 128-byte lines
-    // either side of a strip run at the same time under the same L2 (in plain round-robin order horizontal neighbours sit
-    // on 8 different XCDs and every one of them fetches the shared lines from HBM: 5x the algorithmic read, measured).
-    unsigned blk = blockIdx.x, blk_end = nblk, blk_step = gridDim.x;
-    if ((gridDim.x & 7u) == 0 && nblk >= gridDim.x) {
-        const unsigned chunk = (nblk + 7u) >> 3;
-        blk = (blockIdx.x & 7u) * chunk + (blockIdx.x >> 3);
-        blk_end = min(nblk, ((blockIdx.x & 7u) + 1u) * chunk);
-        blk_step = gridDim.x >> 3;
-    }
     for (; blk < blk_end; blk += blk_step) {
         const int b = (int)(blk / blocks_per_clip);
         const unsigned rr = blk - (unsigned)b * blocks_per_clip;
@@ -283,7 +297,7 @@ __global__ __launch_bounds__(NTH32, 2) void wino32_kernel(ConvArgs p) {
                 *reinterpret_cast<float2*>(wtab + lane * 2) = t;
             }
             if (EPI && lane < 32)
-                *reinterpret_cast<float2*>(wes + lane * 2) = make_float2(p.epi_scale[lane], p.epi_shift[(size_t)b * p.epi_shift_bs + lane]);
+                *reinterpret_cast<float2*>(wes + lane * 2) = make_float2(p.epi_scale[n0 + lane], p.epi_shift[(size_t)b * p.epi_shift_bs + n0 + lane]);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same wave writes and reads: in-order LDS, no barrier
         }
 
@@ -469,7 +483,7 @@ __global__ __launch_bounds__(NTH32, 2) void wino32_kernel(ConvArgs p) {
 #endif
         if (!(EXPF & 2)) {
             if constexpr (OWN_EPI)
-                w32_epilogue<FLAGS>(p, acc, b, oy, ox, kq, lds_bias, reinterpret_cast<const float2*>(wes),
+                w32_epilogue<FLAGS>(p, acc, b, n0, oy, ox, kq, lds_bias, reinterpret_cast<const float2*>(wes),
                                     reinterpret_cast<const float2*>(lds_pw));
             else
                 wino_epilogue<FLAGS>(p, acc, b, 0, 0, oy, ox, lane, lds_bias, wes, weh, lds_pw, lds_pb, lds_mw);
@@ -535,8 +549,10 @@ hipError_t launch32(const ConvArgs& p, hipStream_t stream) {
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
         return n > 0 ? n : 256;
     }();
-    const long nblk = (long)(p.W / 32) * ((p.H / 2 + NW32 - 1) / NW32) * p.B;
-    const unsigned grid = (unsigned)(nblk < ncu ? nblk : ncu);  // persistent: one workgroup per CU, every wave's loop is bounded
+    const long ns = p.N / 32;  // 32-cout slices: a workgroup serves one of them
+    const long nblk = (long)(p.W / 32) * ((p.H / 2 + NW32 - 1) / NW32) * p.B * ns;
+    // persistent: one workgroup per CU, every wave's loop is bounded; a multiple of the slice count
+    const unsigned grid = (unsigned)(nblk < ncu ? nblk : ncu / ns * ns);
 #ifdef LASS_CONV_DIAG
     ConvArgs q = p;
     static long long* dbuf = nullptr;
@@ -569,9 +585,15 @@ bool lass_wino32_supported(ConvKind kind, const ConvArgs& p) {
     static const int kind_mask = [] { const char* e = getenv("LASS_W32_KINDS"); return e ? atoi(e) : 0xff; }();  // debugging aid
     if (!((kind_mask >> (int)kind) & 1)) return false;
     if (p.pool_out && p.pool_h != 2) return false;
-    if (p.N != 32 || p.Nw != 32 || p.W < 32 || (p.W % 32) != 0 || (p.H % 2) != 0 || !p.w_wino32) return false;
+    if ((p.N != 32 && p.N != 64) || p.Nw != p.N || p.W < 32 || (p.W % 32) != 0 || (p.H % 2) != 0 || !p.w_wino32) return false;
     // 32-bit byte offsets inside one clip's tensors
     if ((unsigned long long)p.Cin * p.H * p.W * 4ull > 0xFFFF0000ull) return false;
+    if (p.N == 64) {  // two 32-cout slices (encoder_block2): the variants whose resident weights fit LDS (LASS_W32_N64=0: off)
+        static const bool n64 = [] { const char* e = getenv("LASS_W32_N64"); return !e || atoi(e) != 0; }();
+        if (!n64) return false;
+        if (kind == CONV1_ACT) return p.Cin == 32 || p.Cin == 64;
+        return kind == CONV2_SHORTCUT && p.Cin == 64 && p.Cin2 == 32 && p.w2_wino32 && !p.mask_re;
+    }
     switch (kind) {
         case CONV1_ACT: return p.Cin == 32 || p.Cin == 64;
         case CONV1_ACT_PRE: return p.Cin == 32;
@@ -607,18 +629,25 @@ hipError_t lass_launch_wino32(ConvKind kind, const ConvArgs& p, hipStream_t stre
                 return p.Cin2 == 64 ? launch32<F_PHASEB | F_BIAS | F_MASK, 32, 64>(p, stream)
                                     : launch32<F_PHASEB | F_BIAS | F_MASK, 32, 128>(p, stream);
             }
+            if (p.Cin == 64) return launch32<F_PHASEB | F_BIAS, 64, 32>(p, stream);
             return p.Cin2 == 64 ? launch32<F_PHASEB | F_BIAS, 32, 64>(p, stream) : launch32<F_PHASEB | F_BIAS, 32, 128>(p, stream);
         default:
             return hipErrorInvalidValue;
     }
 }
 
-hipError_t lass_launch_wino32_weights(const float* w, int Cin, float* U, hipStream_t stream) {
-    hipLaunchKernelGGL(wino32_weights_kernel, dim3((unsigned)((32 * Cin + 255) / 256)), dim3(256), 0, stream, w, Cin, U);
+// w: (Cout, Cin, 3, 3) with Cout a multiple of 32 -> U: one resident image (512 * Cin floats) per 32-cout slice
+hipError_t lass_launch_wino32_weights(const float* w, int Cout, int Cin, float* U, hipStream_t stream) {
+    for (int s = 0; s < Cout / 32; ++s)
+        hipLaunchKernelGGL(wino32_weights_kernel, dim3((unsigned)((32 * Cin + 255) / 256)), dim3(256), 0, stream,
+                           w + (size_t)s * 32 * Cin * 9, Cin, U + (size_t)s * 512 * Cin);
     return hipGetLastError();
 }
 
-hipError_t lass_launch_wino32_shortcut_weights(const float* w, int Cin, float* U, hipStream_t stream) {
-    hipLaunchKernelGGL(wino32_shortcut_weights_kernel, dim3((unsigned)((32 * Cin + 255) / 256)), dim3(256), 0, stream, w, Cin, U);
+// w: (Cout, Cin) -> U: 128 * Cin floats per 32-cout slice
+hipError_t lass_launch_wino32_shortcut_weights(const float* w, int Cout, int Cin, float* U, hipStream_t stream) {
+    for (int s = 0; s < Cout / 32; ++s)
+        hipLaunchKernelGGL(wino32_shortcut_weights_kernel, dim3((unsigned)((32 * Cin + 255) / 256)), dim3(256), 0, stream,
+                           w + (size_t)s * 32 * Cin, Cin, U + (size_t)s * 128 * Cin);
     return hipGetLastError();
 }
