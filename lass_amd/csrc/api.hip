@@ -858,6 +858,9 @@ int lass_finalize(lass_ctx* c, int compute_mode) {
                 if (dev_alloc(c, &rb.u1r, ns * 512 * rb.cin) || dev_alloc(c, &rb.u2r, ns * 512 * rb.cout)) return LASS_ERR_HIP;
                 HIP_TRY(c, lass_launch_wino32_weights(w1, rb.cout, rb.cin, rb.u1r, st));
                 HIP_TRY(c, lass_launch_wino32_weights(w2, rb.cout, rb.cout, rb.u2r, st));
+            } else if (rb.cout == 128 && rb.cin == 64) {  // encoder_block3.conv1 as four slices (conv2's weights do not fit)
+                if (dev_alloc(c, &rb.u1r, (size_t)4 * 512 * rb.cin)) return LASS_ERR_HIP;
+                HIP_TRY(c, lass_launch_wino32_weights(w1, rb.cout, rb.cin, rb.u1r, st));
             }
         }
         rb.wsc = nullptr;

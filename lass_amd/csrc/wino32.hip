@@ -585,14 +585,14 @@ bool lass_wino32_supported(ConvKind kind, const ConvArgs& p) {
     static const int kind_mask = [] { const char* e = getenv("LASS_W32_KINDS"); return e ? atoi(e) : 0xff; }();  // debugging aid
     if (!((kind_mask >> (int)kind) & 1)) return false;
     if (p.pool_out && p.pool_h != 2) return false;
-    if ((p.N != 32 && p.N != 64) || p.Nw != p.N || p.W < 32 || (p.W % 32) != 0 || (p.H % 2) != 0 || !p.w_wino32) return false;
+    if ((p.N != 32 && p.N != 64 && p.N != 128) || p.Nw != p.N || p.W < 32 || (p.W % 32) != 0 || (p.H % 2) != 0 || !p.w_wino32) return false;
     // 32-bit byte offsets inside one clip's tensors
     if ((unsigned long long)p.Cin * p.H * p.W * 4ull > 0xFFFF0000ull) return false;
-    if (p.N == 64) {  // two 32-cout slices (encoder_block2): the variants whose resident weights fit LDS (LASS_W32_N64=0: off)
-        static const bool n64 = [] { const char* e = getenv("LASS_W32_N64"); return !e || atoi(e) != 0; }();
-        if (!n64) return false;
+    if (p.N > 32) {  // 32-cout slices (encoder_block2, encoder_block3.conv1): the variants whose resident weights fit LDS
+        static const int nmax = [] { const char* e = getenv("LASS_W32_NMAX"); return e ? atoi(e) : 128; }();  // A/B: 32 = no slices
+        if (p.N > nmax) return false;
         if (kind == CONV1_ACT) return p.Cin == 32 || p.Cin == 64;
-        return kind == CONV2_SHORTCUT && p.Cin == 64 && p.Cin2 == 32 && p.w2_wino32 && !p.mask_re;
+        return kind == CONV2_SHORTCUT && p.N == 64 && p.Cin == 64 && p.Cin2 == 32 && p.w2_wino32 && !p.mask_re;
     }
     switch (kind) {
         case CONV1_ACT: return p.Cin == 32 || p.Cin == 64;

@@ -259,7 +259,8 @@ def test_wino32_resident_kernel_vs_oracle_and_wino(synthetic_sd, oracle_sd, monk
     """wino32.hip (weights-resident persistent kernel of the 32-cout full-resolution layers, resunet.py:147-165 at the
     shapes of :315-323,408-418) against the oracle and against wino.hip (LASS_WINO32=0), block by block: encoder_block1 with
     its fused avg-pool (CONV1_ACT / CONV2_IDENT), decoder_block6's ConvBlockRes (Cin = 64 conv1, conv2 + transform-domain
-    shortcut), encoder_block2 (32 -> 64 as two 32-cout slices: conv1, conv2 with Cin = 64 + shortcut + pool).  Shapes cover border-only images (one block column), strips that do not fill a block of 8 (H/2 = 9, 20),
+    shortcut), encoder_block2 (32 -> 64 as two 32-cout slices: conv1, conv2 with Cin = 64 + shortcut + pool), encoder_block3 (conv1
+    64 -> 128 as four slices).  Shapes cover border-only images (one block column), strips that do not fill a block of 8 (H/2 = 9, 20),
     and B = 3."""
     from lass_amd.engine import Engine
     from oracle import resunet as orr
@@ -277,7 +278,8 @@ def test_wino32_resident_kernel_vs_oracle_and_wino(synthetic_sd, oracle_sd, monk
         y1, p1 = e.encoder_block("base.encoder_block1", x1.to(DEV), shift, 32, (2, 2))
         y6 = e.convblock("base.decoder_block6.conv_block2", x6.to(DEV), shift, 32)
         y2, p2 = e.encoder_block("base.encoder_block2", x1.to(DEV), shift, 64, (2, 2))   # two 32-cout slices
-        outs[sw] = (y1.cpu(), p1.cpu(), y6.cpu(), y2.cpu(), p2.cpu())
+        y3, _ = e.encoder_block("base.encoder_block3", x6.to(DEV), shift, 128, (2, 2))  # conv1 as four slices
+        outs[sw] = (y1.cpu(), p1.cpu(), y6.cpu(), y2.cpu(), p2.cpu(), y3.cpu())
     r1 = orr.conv_block_res(oracle_sd, "base.encoder_block1.conv_block1", x1,
                             orr.film(oracle_sd, cond, "encoder_block1->conv_block1->beta1"),
                             orr.film(oracle_sd, cond, "encoder_block1->conv_block1->beta2"))
@@ -287,7 +289,10 @@ def test_wino32_resident_kernel_vs_oracle_and_wino(synthetic_sd, oracle_sd, monk
     r2 = orr.conv_block_res(oracle_sd, "base.encoder_block2.conv_block1", x1,
                             orr.film(oracle_sd, cond, "encoder_block2->conv_block1->beta1"),
                             orr.film(oracle_sd, cond, "encoder_block2->conv_block1->beta2"))
-    refs = (r1, torch.nn.functional.avg_pool2d(r1, (2, 2)), r6, r2, torch.nn.functional.avg_pool2d(r2, (2, 2)))
+    r3 = orr.conv_block_res(oracle_sd, "base.encoder_block3.conv_block1", x6,
+                            orr.film(oracle_sd, cond, "encoder_block3->conv_block1->beta1"),
+                            orr.film(oracle_sd, cond, "encoder_block3->conv_block1->beta2"))
+    refs = (r1, torch.nn.functional.avg_pool2d(r1, (2, 2)), r6, r2, torch.nn.functional.avg_pool2d(r2, (2, 2)), r3)
     for got, old, ref in zip(outs["1"], outs["0"], refs):
         assert got.shape == ref.shape
         assert _relerr(got, ref) < 5e-6, _relerr(got, ref)     # the bar of test_convblock_vs_oracle
