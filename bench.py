@@ -425,6 +425,14 @@ def main():
             "whole_step_tflops": tot_m / (dt_m / 5) / 1e12, "gmac_per_clip": tot_m / 2e9 / Bm,
             "workspace_gib": em.workspace_bytes(Bm, Lm) / 2.0 ** 30,
             "kernel_ms_per_step": {k: v[0] / 2 for k, v in pm.items()}}
+        # the same clip in the bf16 compute modes (f32 tensors between the blocks): 3 warm-up + 5 timed steps each
+        for mm in ("bf16x3", "bf16"):
+            ms.set_compute_dtype(mm)
+            em = ms.engine
+            dt_b = timed(em, 5, 3, io)
+            assert not check or torch.isfinite(io[2]).all()
+            modes["multistft_30s_32k"][mm] = {"ms_per_clip": dt_b / 5 / Bm * 1e3, "clips_s": world * Bm * 5 / dt_b,
+                                               "realtime_factor": world * Bm * 5 / dt_b * 30.0}
         del em, ms, io, mix_m
         gc.collect()
         torch.cuda.empty_cache()
@@ -434,7 +442,7 @@ def main():
         total_flops = 2.0 * B * sum(r["macs"] for r in rows)
         traffic = traffic_fields(args.dtype, alg_bytes_launch_of(head), (B, L) == (16, 160000))
         alg_bytes_launch = alg_bytes_launch_of(head)
-        kernel = {"f32": "wino_kernel<...> x26: 3x3 convs as Winograd F(2x2,3x3) on v_mfma_f32_16x16x4_f32 + fused 1x1 "
+        kernel = {"f32": "wino_kernel<...> x19 + wino32_kernel<...> x7: 3x3 convs as Winograd F(2x2,3x3) on v_mfma_f32_16x16x4_f32 + fused 1x1 "
                          "shortcuts (conv3x3_mfma class)" if wino else "conv_kernel (direct f32 MFMA)",
                   "bf16": "conv_bf16_kernel x26: direct 3x3 + fused 1x1 shortcuts on v_mfma_f32_32x32x16_bf16",
                   "bf16x3": "conv_bf16_kernel (split operands, 3 MFMAs per product) x26"}[args.dtype]

@@ -89,9 +89,8 @@ int lass_finalize(lass_ctx* ctx, int compute_mode);
 
 /* Bytes of workspace `lass_separate` needs for B clips of L samples.
  * Limits: B >= 1, L > n_fft/2, and the largest per-clip tensor - decoder_block6's concat, (32 + 32*n_windows) channels x
- * padded frames x n_fft/2 bins, f32 - below 4 GiB (f32 mode with the Winograd kernels) or 2 GiB (other modes): the
- * kernels address one clip's tensors with 32-bit byte offsets.  ResUNet30: 327 s / 163 s at 16 kHz; multi-STFT model:
- * 40.9 s at 32 kHz.  Longer clips are an LASS_ERR_ARG here and in lass_separate; the reference's own long-form route,
+ * padded frames x n_fft/2 bins, f32 - below 4 GiB (2 GiB with the direct f32 kernels, LASS_WINO=0): the kernels address
+ * one clip's tensors with unsigned 32-bit byte offsets.  ResUNet30: 327 s at 16 kHz; multi-STFT model: 40.9 s at 32 kHz.  Longer clips are an LASS_ERR_ARG here and in lass_separate; the reference's own long-form route,
  * chunk_inference (resunet.py:655-714), stays available. */
 int lass_workspace_bytes(const lass_ctx* ctx, int B, int L, size_t* bytes);
 

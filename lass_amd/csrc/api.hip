@@ -561,8 +561,9 @@ size_t bump(size_t& total, size_t floats) {
 
 // The conv kernels address one clip's tensors through 32-bit buffer descriptors and byte offsets, so the largest per-clip
 // tensor (decoder_block6's concat at full resolution, f32) bounds the clip length: below 4 GiB for the f32 Winograd
-// kernels (all offset arithmetic unsigned), below 2 GiB for the direct and bf16 kernels.  ResUNet30 at 16 kHz:
-// 131 072 B per frame -> 2^31 at 16 384 frames (163 s); the multi-STFT model (128 ch x 1024 bins): 524 288 B per frame ->
+// and the bf16 kernels (all offset arithmetic unsigned; both exercised by the 3.15-GB concat of the 30 s @ 32 kHz multi-STFT
+// clip), below 2 GiB for the direct f32 kernels (LASS_WINO=0).  ResUNet30 at 16 kHz: 131 072 B per frame -> 2^32 at 32 768
+// frames (327 s); the multi-STFT model (128 ch x 1024 bins): 524 288 B per frame ->
 // 2^32 at 8 192 frames (40.9 s at 32 kHz).  Longer inputs go through chunk_inference.
 int make_plan(const lass_ctx* c, int B, int L, Plan* pl) {
     const Geometry& g = c->g;
@@ -571,7 +572,7 @@ int make_plan(const lass_ctx* c, int B, int L, Plan* pl) {
     pl->T = 1 + L / LASS_HOP;
     pl->Tp = (pl->T + 31) / 32 * 32;
     const size_t clip_max = (size_t)c->dec_cat[5] * pl->Tp * g.fcrop * sizeof(float);
-    const size_t limit = (c->compute_mode == LASS_COMPUTE_F32 && c->wino) ? 0xFFFF0000ull : 0x7FFFFFFFull;
+    const size_t limit = (c->compute_mode != LASS_COMPUTE_F32 || c->wino) ? 0xFFFF0000ull : 0x7FFFFFFFull;
     if (clip_max > limit) return LASS_ERR_ARG;
     size_t& t = pl->total;
     t = 0;
@@ -779,8 +780,6 @@ int lass_finalize(lass_ctx* c, int compute_mode) {
     if (!c) return LASS_ERR_ARG;
     if (compute_mode != LASS_COMPUTE_F32 && compute_mode != LASS_COMPUTE_BF16 && compute_mode != LASS_COMPUTE_BF16X3)
         return fail(c, LASS_ERR_ARG, "unsupported compute mode");
-    if (c->g.variant != 0 && compute_mode != LASS_COMPUTE_F32)
-        return fail(c, LASS_ERR_ARG, "the multi-STFT model computes in f32 only");
     c->compute_mode = compute_mode;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipDeviceSynchronize());  // replays of graphs that hold the old derived buffers have drained
@@ -1173,7 +1172,7 @@ static int separate_impl(lass_ctx* c, const float* mixture, const Components* co
         return fail(c, LASS_ERR_ARG, std::string(who) + ": need B >= 1 and " + std::to_string(g.nfft / 2) +
                                          " < L, with decoder_block6's concat (" + std::to_string(c->dec_cat[5]) +
                                          " ch x frames x " + std::to_string(g.fcrop) + " bins, f32) below " +
-                                         ((c->compute_mode == LASS_COMPUTE_F32 && c->wino) ? "4" : "2") +
+                                         ((c->compute_mode != LASS_COMPUTE_F32 || c->wino) ? "4" : "2") +
                                          " GiB per clip (longer clips: ResUNet30.chunk_inference)");
     if (workspace_bytes < pl.total)
         return fail(c, LASS_ERR_WORKSPACE, "workspace too small: need " + std::to_string(pl.total) + " bytes");

@@ -44,11 +44,6 @@ class ResUNet30(_ResUNet30):
     def _make_engine(self, dev) -> Engine:
         return Engine(dev, multistft=(arch.MS_N_FFT, self.win_lengths, arch.MS_MASK_WINDOW))
 
-    def set_compute_dtype(self, compute_dtype: str):
-        if compute_dtype != "f32":
-            raise NotImplementedError("the multi-STFT separator computes in f32 only")
-        return super().set_compute_dtype(compute_dtype)
-
     @torch.no_grad()
     def forward(self, input_dict: Dict, target_waveform: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
         """resunet_with_multistft.py:233-241.  Returns {'waveform': (B, L)} for the precomputed form (what the

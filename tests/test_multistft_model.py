@@ -211,6 +211,15 @@ def test_multistft_config5_30s_32khz_vs_oracle(ms_model, ms_sd):
     ref = oms.forward(sd, {"mixture": torch.from_numpy(mix)[:, None], "condition": torch.from_numpy(cond)})["waveform"]
     err, sig = _rms(out.cpu() - ref), _rms(ref)
     assert sig > 1e-3 and err <= 1e-5, (err, sig)
+    # the bf16 compute modes at the same size (their kernels read the 3.15-GB concat through unsigned offsets too)
+    try:
+        for mode, bar in (("bf16x3", 1e-5), ("bf16", 5e-2 * sig)):
+            ms_model.set_compute_dtype(mode)
+            o2 = ms_model({"mixture": torch.from_numpy(mix)[:, None].to(DEV), "condition": torch.from_numpy(cond).to(DEV)})["waveform"]
+            e2 = _rms(o2.cpu() - ref)
+            assert 1e-8 < e2 <= bar, (mode, e2)
+    finally:
+        ms_model.set_compute_dtype("f32")
 
 
 @pytest.mark.gpu
@@ -220,8 +229,35 @@ def test_multistft_limits_and_modes(ms_model):
     with pytest.raises(LassError):
         eng.workspace_bytes(1, 8192 * 160)      # concat would reach 4 GiB per clip
     assert eng.workspace_bytes(1, 8100 * 160) > 0
-    with pytest.raises(NotImplementedError):
+    # the same limit in the bf16 modes (their kernels' offset arithmetic is unsigned too)
+    try:
         ms_model.set_compute_dtype("bf16")
+        eng = ms_model.engine
+        with pytest.raises(LassError):
+            eng.workspace_bytes(1, 8192 * 160)
+        assert eng.workspace_bytes(1, 8100 * 160) > 0
+    finally:
+        ms_model.set_compute_dtype("f32")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,bar", [("bf16x3", 1e-5), ("bf16", 5e-2)])
+def test_multistft_bf16_modes_vs_oracle(ms_model, ms_sd, mode, bar):
+    """The bf16-MFMA compute modes on the multi-STFT separator (f32 tensors between the blocks): the split-operand mode is
+    held to the f32 bar (1e-5 RMS), plain bf16 to 5 % of the signal RMS; ragged length, B = 2 and B = 1."""
+    sd = orr.to_torch(ms_sd)
+    try:
+        ms_model.set_compute_dtype(mode)
+        for B, L in ((2, 16000), (1, 8000 + 77)):
+            _, mix = synthetic.make_mixtures(B, L)
+            cond = synthetic.make_condition(B)
+            ref = oms.forward(sd, {"mixture": torch.from_numpy(mix)[:, None], "condition": torch.from_numpy(cond)})["waveform"]
+            out = ms_model({"mixture": torch.from_numpy(mix)[:, None].to(DEV), "condition": torch.from_numpy(cond).to(DEV)})["waveform"]
+            err = _rms(out.cpu() - ref)
+            assert err <= (bar if mode == "bf16x3" else bar * _rms(ref)), (mode, B, L, err)
+            assert err > 1e-8   # really another arithmetic than the f32 path (1.7e-8 against the oracle)
+    finally:
+        ms_model.set_compute_dtype("f32")
 
 
 @pytest.mark.gpu

@@ -42,3 +42,9 @@ for B in (1, 2):
     dt = timeit(lambda: ms({'mixture': xb, 'condition': cb}))
     print(f'multi-STFT separator whole-clip forward B={B}: {dt/B*1e3:.1f} ms/clip  {B/dt:.2f} clips/s  ({30.0*B/dt:.0f}x real time)  '
           f'{2*gmac*B/dt/1e3:.1f} algorithmic TFLOP/s ({gmac:.0f} GMAC/clip), workspace {ms.engine.workspace_bytes(B, L)/2**30:.1f} GiB', flush=True)
+# the same model and clip in the bf16 compute modes (f32 tensors between the blocks)
+c1 = torch.from_numpy(synthetic.make_condition(1)).cuda()
+for mode in ("bf16x3", "bf16"):
+    ms.set_compute_dtype(mode)
+    dt = timeit(lambda: ms({'mixture': x, 'condition': c1}), n=5)
+    print(f'multi-STFT separator whole-clip forward B=1, compute_dtype={mode}: {dt*1e3:.1f} ms/clip  {1/dt:.1f} clips/s  ({30.0/dt:.0f}x real time)', flush=True)
