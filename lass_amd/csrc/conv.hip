@@ -24,6 +24,7 @@
 #include <vector>
 #include "kernels.h"
 #include "conv_common.h"
+#include "wino_common.h"  // block_coords: the XCD-aware workgroup order
 
 namespace {
 
@@ -261,11 +262,12 @@ __global__ __launch_bounds__(NTHREADS) void conv_kernel_db(ConvArgs p) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.z;
-    const int n0 = blockIdx.y * NT;
+    int bx_, by_, b;
+    block_coords(p, bx_, by_, b);  // 1-D grid: the cout blocks of one input tile on one XCD (wino_common.h)
+    const int n0 = by_ * NT;
     const int tiles_x = p.W / PW;
-    const int y0 = (blockIdx.x / tiles_x) * PHT;
-    const int x0 = (blockIdx.x % tiles_x) * PW;
+    const int y0 = (bx_ / tiles_x) * PHT;
+    const int x0 = (bx_ % tiles_x) * PW;
     const int HW = p.H * p.W;
     const int khalf = lane >> 5, j = lane & 31;
     const int ty = j / PW, tx = j % PW;
@@ -353,10 +355,11 @@ __global__ __launch_bounds__(NTHREADS) void conv_kernel_sb(ConvArgs p) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.z;
-    const int n0 = blockIdx.y * NT;
+    int bx_, by_, b;
+    block_coords(p, bx_, by_, b);  // 1-D grid: the cout blocks of one input tile on one XCD (wino_common.h)
+    const int n0 = by_ * NT;
     const int tiles_x = p.W / PW;
-    const int y0 = (blockIdx.x / tiles_x) * PHT, x0 = (blockIdx.x % tiles_x) * PW;
+    const int y0 = (bx_ / tiles_x) * PHT, x0 = (bx_ % tiles_x) * PW;
     const int HW = p.H * p.W;
     const int khalf = lane >> 5, j = lane & 31;
     const int ty = j / PW, tx = j % PW;
@@ -496,7 +499,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_kernel_sb(ConvArgs p) {
 #ifdef LASS_CONV_DIAG
     if (p.dbg && tid == 0) {
         const long long k_c3 = clock64(), k_r3 = wall_clock64();
-        long long* d = p.dbg + 8 * ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+        long long* d = p.dbg + 8 * (size_t)blockIdx.x;
         d[0] = dsum[0]; d[1] = dsum[1]; d[2] = dsum[2]; d[3] = dsum[3];
         d[4] = k_c1 - k_c0;   // prologue
         d[5] = k_c3 - k_c0;   // whole block, shader cycles
@@ -547,7 +550,14 @@ template <int TAPS, int NCO, int NPX, int PW, int FLAGS>
 hipError_t launch_one(const ConvArgs& p0, hipStream_t stream) {
     constexpr int PHT = 4 * NPX * (32 / PW);
     ConvArgs p = p0;
-    dim3 grid((p.W / PW) * ((p.H + PHT - 1) / PHT), p.N / (32 * NCO), p.B);
+    // 1-D grid decoded by block_coords(): the gy cout blocks of a (tile, clip) pair run on ONE XCD - a transposed conv is a
+    // 1-tap conv with 4 x Cout output channels, i.e. 2-12 cout blocks that all read the same input tile (in the natural
+    // 3-D order they ran a whole grid row apart and the tile came from HBM once per block: 2x the input at decoder_block6)
+    static const int xcd = [] { const char* e = getenv("LASS_XCD_MAP"); return e ? atoi(e) : 2; }();
+    p.gx = (p.W / PW) * ((p.H + PHT - 1) / PHT);
+    p.gy = p.N / (32 * NCO);
+    p.xcd_map = (xcd && ((long)p.gx * p.B) % 8 == 0 && (p.gy > 1 || xcd == 2)) ? xcd : 0;
+    dim3 grid((unsigned)((long)p.gx * p.gy * p.B));
 #ifdef LASS_CONV_DIAG
     static long long* dbuf = nullptr;
     static size_t dcap = 0;

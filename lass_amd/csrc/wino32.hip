@@ -18,7 +18,8 @@
 // instruction is therefore paid in full on top of the MFMA time, interleaved or not; so the kernel issues as few of them as
 // it can (per k-step of 32 MFMAs: 32 adds for B^T d B, 48 for the prologue where there is one, 8 loads, 8 LDS reads), in ONE
 // block between two runs of 32 back-to-back MFMAs, and nothing else (pins between single MFMAs cost a v_mov and an s_nop
-// each when they were tried).
+// each when they were tried).  Also tried and not kept (profiles/r03/ubench/): packed-f32 arithmetic for
+// the transforms, 16-byte patch loads, the next strip's first patches requested in front of the epilogue.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -43,18 +44,9 @@ constexpr int NW32 = 8;           // waves per workgroup: two per SIMD, one work
 #ifndef W32_NOP
 #define W32_NOP "s_nop 1\n\t"
 #endif
-#ifndef W32_APF
-#define W32_APF 2
-#endif
-constexpr int APF = W32_APF;      // A-fragment read-ahead in MFMA groups
 constexpr int NTH32 = 64 * NW32;
 
 typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
-// Opaque use-and-redefine of registers: the values exist in registers at this point of the program and nothing computed
-// from them can be scheduled above it (asm volatile statements and sched_barriers keep their order).  This is what keeps
-// a slice of the patch transform inside the MFMA group it was written behind (hipcc otherwise gathers the slices).
-#define PIN2(a, b) asm volatile("" : "+v"(a), "+v"(b))
-#define PIN4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
 typedef __attribute__((address_space(3))) const float lds_cfloat;  // LDS pointers that stay LDS pointers (ds_read, not flat)
 typedef __attribute__((address_space(3))) const f32x4 lds_cf32x4;
 
