@@ -1,5 +1,6 @@
 """CPU-side tests: C-ABI library loads and exports every symbol of include/lass_hip.h (no compute without a GPU),
 host logic (sharding, gather over gloo with world_size 2, wav I/O, metrics dB math, module/state_dict mirror)."""
+import json
 import os
 import re
 import subprocess
@@ -170,3 +171,51 @@ def test_gather_rows_gloo_world2(tmp_path, n):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert f"GATHER_OK {n} 2" in r.stdout
+
+
+# ---- bench.py: the PMC traffic number is only reported for the kernels it was measured at ----------------------------
+def _import_bench():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import bench
+    return bench
+
+
+def test_bench_traffic_reported_only_at_matching_source_hash(monkeypatch, tmp_path):
+    """roofline.traffic comes from a committed rocprofv3 --pmc summary (bench.py cannot read counters itself): it is
+    reported only when the summary's `source_hash` equals the hash of the kernel sources in use, otherwise null +
+    `traffic_stale` - a measurement of other kernels is never passed off as this run's."""
+    bench = _import_bench()
+    import __graft_entry__ as ge
+    prof = tmp_path / "profiles" / "r99"
+    prof.mkdir(parents=True)
+    rec = {"traffic_bytes_per_launch": 1.5e9, "source_hash": ge._src_hash(), "fetch_calibration": {"x": 1}}
+    (prof / "conv_traffic_f32.json").write_text(json.dumps(rec))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    got = bench.traffic_fields("f32", 1.0e9)
+    assert got["traffic"] == 1.5e9 and got["traffic_over_algorithmic"] == pytest.approx(1.5)
+    assert got["traffic_stale"] is False and got["traffic_source_hash"] == ge._src_hash()
+    rec["source_hash"] = "0" * 64
+    (prof / "conv_traffic_f32.json").write_text(json.dumps(rec))
+    got = bench.traffic_fields("f32", 1.0e9)
+    assert got["traffic"] is None and got["traffic_over_algorithmic"] is None and got["traffic_stale"] is True
+    assert "not reported" in got["traffic_source"]
+    # no summary for the dtype, or switched off (other workload than B=16 x 10 s): null without a stale flag
+    assert bench.traffic_fields("bf16", 1.0e9) == {"traffic": None, "traffic_over_algorithmic": None, "traffic_source": None}
+    assert bench.traffic_fields("f32", 1.0e9, enabled=False)["traffic"] is None
+
+
+def test_committed_traffic_profiles_are_complete():
+    """The newest profiles/rNN/conv_traffic_<dtype>.json files carry what bench.py and the judge read: bytes per launch split
+    into fetch and write, the launch count, the workload and the hash of the kernel sources they were measured at."""
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for dtype in ("f32", "bf16"):
+        files = sorted(glob.glob(os.path.join(root, "profiles", "r*", f"conv_traffic_{dtype}.json")))
+        assert files, dtype
+        d = json.load(open(files[-1]))
+        assert d["dtype"] == dtype and d["launches"] >= 20
+        assert d["traffic_bytes_per_launch"] == pytest.approx(d["fetch_bytes_per_launch"] + d["write_bytes_per_launch"], rel=1e-9)
+        assert re.fullmatch(r"[0-9a-f]{64}", d["source_hash"])
+        assert 1.0 <= d["traffic_bytes_per_launch"] / {"f32": 862090791.4, "bf16": 431045395.7}[dtype] < 3.0
