@@ -489,6 +489,15 @@ int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int
         HIP_TRY(c, lass_launch_enc1_fused_bf16(p, q, st));
         return 0;
     }
+    if (rb.cin != rb.cout) { q.in2 = x; q.in2_bs = x_bs; q.Cin2 = rb.cin; q.w2 = rb.wsc; q.bias = rb.bsc; }
+    // ... and decoder_block6's ConvBlockRes with the output head behind it (conv1 from the activated cat copy, the 1x1
+    // shortcut from the raw one)
+    if (bf2 && !x0 && c->fuse_block && c->compute_mode == LASS_COMPUTE_BF16 && cat_in && mh && rb.cin != rb.cout &&
+        lass_dec6_fused_bf16_supported(p, q)) {
+        ProfScope ps(c, st, P_CONV3X3);
+        HIP_TRY(c, lass_launch_dec6_fused_bf16(p, q, st));
+        return 0;
+    }
     if (int r1 = launch_conv1()) return r1;
     ProfScope ps(c, st, P_CONV3X3);
     if (rb.cin == rb.cout) {
@@ -501,7 +510,6 @@ int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int
         else
             HIP_TRY(c, lass_launch_conv(x0 ? CONV2_IDENT_PRE : CONV2_IDENT, q, st));
     } else {
-        q.in2 = x; q.in2_bs = x_bs; q.Cin2 = rb.cin; q.w2 = rb.wsc; q.bias = rb.bsc;
         if (bf2)
             HIP_TRY(c, lass_launch_conv_bf16(CONV2_SHORTCUT, q, st));
         else if (wino2 && c->wino32 && lass_wino32_supported(CONV2_SHORTCUT, q))

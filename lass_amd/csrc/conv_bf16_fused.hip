@@ -216,6 +216,214 @@ __global__ __launch_bounds__(NTHREADS) void enc1_fused_bf16_kernel(ConvArgs p, C
                                                                  lds_act);
 }
 
+
+// ---- decoder_block6's ConvBlockRes (resunet.py:147-165 at the shape of :408-418) with the output head, ONE kernel ----------
+//   cat (activated blocked-bf16 copy, 64 channels, 12 x 36 tile)  --global -> registers -> LDS, 4 chunks of 16 channels-->
+//   conv1 (3x3, 64 -> 32) over the 10 x 34 pixels conv2 needs, + bn2/FiLM/leaky, zero outside the image --> LDS image
+//   conv2 (3x3, 32 -> 32) over it  +  the 1x1 shortcut over the RAW copy of the cat (operands straight from global memory
+//   into the MFMA: a lane's B fragment is one 16-byte unit of the blocked layout, its A fragment one unit of the weights)
+//   + bias  -->  after_conv + complex ratio mask (store_tile's F_MASK epilogue): out_real / out_imag.
+// The 32-channel intermediate (0.54 GB written and read back with its halo per step) never leaves the CU.
+// p: conv1 (CONV1_ACT arguments in the blocked pipeline: in_bf16 = activated cat copy, w_bf16, epilogue tables);
+// q: conv2 (CONV2_SHORTCUT arguments: w_bf16, in2_bf16 = raw cat copy, w2_bf16, bias, mask head).
+__global__ __launch_bounds__(NTHREADS) void dec6_fused_bf16_kernel(ConvArgs p, ConvArgs q) {
+    // conv1's image and weight chunk are double-buffered (one barrier per chunk, the next chunk's units and weights arrive
+    // behind this chunk's MFMAs); conv2's weights (2 chunks) take over their regions once conv1 is done: 70 KB per workgroup,
+    // two workgroups per CU
+    constexpr int BUF_U4 = IMG1_U4 + W_U4;  // one (image, weights) buffer
+    static_assert(2 * W_U4 <= 2 * BUF_U4, "conv2's weights must fit the regions conv1 leaves behind");
+    __shared__ uint4 lds4[2 * BUF_U4 + MID_U4 + (64 + 100 + 28) / 4];
+    uint4* mid = lds4 + 2 * BUF_U4;
+    uint4* w2 = lds4;
+    float* tabs = reinterpret_cast<float*>(mid + MID_U4);
+    float* lds_es = tabs;        // conv1 epilogue (bn2 + FiLM) scale / shift
+    float* lds_eh = tabs + 32;
+    float* lds_mw = tabs + 64;   // after_conv weight [3][32] + bias [3]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int khalf = lane >> 5, j = lane & 31;
+    const int tiles_x = p.W / FPW, tiles = tiles_x * ((p.H + FPHT - 1) / FPHT);
+    const int b = blockIdx.x / (unsigned)tiles;
+    const int bxy = blockIdx.x - b * tiles;
+    const int y0 = (bxy / tiles_x) * FPHT, x0 = (bxy % tiles_x) * FPW;
+    const int HW = p.H * p.W;
+
+    if (tid < 32) {
+        lds_es[tid] = p.epi_scale[tid];
+        lds_eh[tid] = p.epi_shift[(size_t)b * p.epi_shift_bs + tid];
+    }
+    if (tid < 99) lds_mw[tid] = tid < 96 ? q.mask_w[tid] : q.mask_b[tid - 96];
+
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) uint4*)lds4;
+    const v4i32 w1_rs = make_rsrc_words(p.w_bf16, 4u * W_U4 * 16u);
+    const v4i32 w2_rs = make_rsrc_words(q.w_bf16, 2u * W_U4 * 16u);
+
+    // ---- this thread's units of the 12 x 36 input tile: one 16-byte unit = 8 channels of a pixel; a chunk = 2 octets --------
+    const uint4* act = reinterpret_cast<const uint4*>(p.in_bf16) + (size_t)b * (p.Cin / 8) * HW;
+    unsigned uoff[NPPI], okbits = 0;
+#pragma unroll
+    for (int k = 0; k < NPPI; ++k) {
+        const int u = min(tid + k * NTHREADS, NPI - 1);
+        const int gy = y0 + u / IPI - 2, gx = x0 + u % IPI - 2;
+        const bool ok = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        uoff[k] = (unsigned)(min(max(gy, 0), p.H - 1) * p.W + min(max(gx, 0), p.W - 1));
+        okbits |= (ok ? 1u : 0u) << k;
+    }
+    uint4 stage[2][2][NPPI];  // two chunks in flight: chunk c in set c & 1
+    auto load_chunk = [&](int c) {
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int k = 0; k < NPPI; ++k) stage[c & 1][o][k] = act[(size_t)(2 * c + o) * HW + uoff[k]];
+    };
+    load_chunk(0);
+    load_chunk(1);
+
+    int mir[3], mic[3];  // conv1's pixel tiles: as in enc1_fused_bf16_kernel
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        int ir = wave + 4 * s, ic = 1 + j;
+        if (s == 2 && wave >= 2) {
+            ir = wave == 2 ? (j >> 1) : IRM;  // wave 3: nothing
+            ic = (j & 1) ? IPM - 1 : 0;
+        }
+        mir[s] = ir;
+        mic[s] = ic;
+    }
+    f32x16 acc1[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[s][r] = 0.f;
+
+    constexpr int NCH = 4;  // 64 input channels
+    auto dma_w1 = [&](int c) {  // weight chunk c -> buffer c & 1
+        for (int piece = wave; piece < W_U4 / 64; piece += 4)
+            lds_dma_16B(w1_rs, (unsigned)lane * 16u, (unsigned)((c * W_U4 + piece * 64) * 16),
+                        lds0 + (unsigned)(((c & 1) * BUF_U4 + IMG1_U4 + piece * 64) * 16));
+    };
+    auto put_chunk = [&](int c) {  // the staged units of chunk c -> image buffer c & 1 (conv zero padding applied here)
+        uint4* img = lds4 + (c & 1) * BUF_U4;
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int k = 0; k < NPPI; ++k) {
+                const int u = tid + k * NTHREADS;
+                const bool ok = (okbits >> k) & 1u;
+                if (u < NPI) img[o * NPI + u] = ok ? stage[c & 1][o][k] : uint4{0u, 0u, 0u, 0u};
+            }
+    };
+    dma_w1(0);
+    put_chunk(0);  // (waits for the units of chunk 0)
+    load_chunk(2);
+    wait_vmcnt<2 * NPPI>();  // weights of chunk 0: only the units of chunk 2 are younger (those of chunk 1 were requested first)
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        if (c + 1 < NCH) dma_w1(c + 1);  // its buffer was last read in chunk c-1: every wave is past that (barrier below)
+        if (c == NCH - 1)                // buffer 0 is free for good: conv2's weights move in behind the last chunk's MFMAs
+            for (int piece = wave; piece < 2 * W_U4 / 64; piece += 4)
+                lds_dma_16B(w2_rs, (unsigned)lane * 16u, (unsigned)piece * 1024u, lds0 + (unsigned)(piece * 1024));
+        const uint4* img = lds4 + (c & 1) * BUF_U4;
+        const bf16x8* abase = reinterpret_cast<const bf16x8*>(img + IMG1_U4) + khalf * 32 + j;
+        const bf16x8* ibase = reinterpret_cast<const bf16x8*>(img) + khalf * NPI;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const bf16x8 a = abase[tap * 64];
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int ir = min(mir[s], IRM - 1);
+                const bf16x8 bb = ibase[(ir + tap / 3) * IPI + mic[s] + tap % 3];
+                acc1[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bb, acc1[s], 0, 0, 0);
+            }
+        }
+        if (c + 1 < NCH) {
+            put_chunk(c + 1);  // image buffer (c+1) & 1 was last read in chunk c-1; the units were requested two chunks ago
+            if (c + 3 < NCH) load_chunk(c + 3);
+            // this wave's weight pieces of chunk c+1 must have landed before the barrier; younger than them are only the
+            // units requested just now (in-order return): with nothing requested, everything is waited for
+            if (c + 3 < NCH) wait_vmcnt<2 * NPPI>(); else wait_vmcnt<0>();
+            __syncthreads();
+        }
+    }
+
+    // ---- shortcut operands (1x1 over the raw cat copy, resunet.py:163): requested here (they arrive behind the epilogue below), contracted behind conv2 -------------
+    const uint4* raw = reinterpret_cast<const uint4*>(q.in2_bf16) + (size_t)b * (q.Cin2 / 8) * HW;
+    const uint4* wsc = reinterpret_cast<const uint4*>(q.w2_bf16);  // [chunk][octet][cout]
+    const int x = x0 + j;
+    unsigned poff[2];
+#pragma unroll
+    for (int px = 0; px < 2; ++px) poff[px] = (unsigned)(min(y0 + wave * 2 + px, q.H - 1) * q.W + x);
+    uint4 sa[NCH], sb[NCH][2];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        sa[c] = wsc[c * 64 + khalf * 32 + j];
+#pragma unroll
+        for (int px = 0; px < 2; ++px) sb[c][px] = raw[(size_t)(2 * c + khalf) * HW + poff[px]];
+    }
+    // accumulators start at the shortcut's bias (resunet.py:163: conv bias of the 1x1)
+    f32x16 acc2[1][2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float bb = q.bias[(r & 3) + 8 * (r >> 2) + 4 * khalf];
+        acc2[0][0][r] = bb;
+        acc2[0][1][r] = bb;
+    }
+    // ---- conv1 epilogue: bn2 + FiLM + leaky (resunet.py:151), zero outside the image, bf16 -> the intermediate image ------
+    {
+        float es4[4][4], eh4[4][4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 a = *reinterpret_cast<const float4*>(lds_es + 8 * g + 4 * khalf);
+            const float4 c = *reinterpret_cast<const float4*>(lds_eh + 8 * g + 4 * khalf);
+            es4[g][0] = a.x; es4[g][1] = a.y; es4[g][2] = a.z; es4[g][3] = a.w;
+            eh4[g][0] = c.x; eh4[g][1] = c.y; eh4[g][2] = c.z; eh4[g][3] = c.w;
+        }
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int ir = mir[s], ic = mic[s];
+            const int gy = y0 - 1 + ir, gx = x0 - 1 + ic;
+            const bool inside = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            if (ir < IRM) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    bf16x4 v;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float t = leaky(acc1[s][4 * g + i] * es4[g][i] + eh4[g][i]);
+                        v[i] = (__bf16)(inside ? t : 0.f);
+                    }
+                    *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(mid + g * NPM + ir * IPM + ic) + khalf * 8) = v;
+                }
+            }
+        }
+    }
+    wait_vmcnt<0>();  // conv2's weights, the shortcut operands
+    __syncthreads();
+
+    // ---- conv2 over the intermediate image ---------------------------------------------------------------------------------
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const bf16x8* bbase = reinterpret_cast<const bf16x8*>(mid) + (2 * c + khalf) * NPM + (wave * 2) * IPM + j;
+        const bf16x8* abase = reinterpret_cast<const bf16x8*>(w2 + c * W_U4) + khalf * 32 + j;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const bf16x8 a = abase[tap * 64];
+#pragma unroll
+            for (int px = 0; px < 2; ++px)
+                acc2[0][px] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bbase[(px + tap / 3) * IPM + tap % 3], acc2[0][px], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int px = 0; px < 2; ++px)
+            acc2[0][px] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, sa[c]), __builtin_bit_cast(bf16x8, sb[c][px]),
+                                                                   acc2[0][px], 0, 0, 0);
+    store_tile<1, 2, FPW, F_MASK, false>(q, acc2, nullptr, nullptr, nullptr, b, 0, y0, x0, lane, wave, lds_mw, nullptr);
+}
+
 }  // namespace
 
 bool lass_enc1_fused_bf16_supported(const ConvArgs& p, const ConvArgs& q) {
@@ -229,5 +437,20 @@ hipError_t lass_launch_enc1_fused_bf16(const ConvArgs& p, const ConvArgs& q, hip
     if (!lass_enc1_fused_bf16_supported(p, q)) return hipErrorInvalidValue;
     const long nblk = (long)(p.W / FPW) * ((p.H + FPHT - 1) / FPHT) * p.B;
     hipLaunchKernelGGL(enc1_fused_bf16_kernel, dim3((unsigned)nblk), dim3(NTHREADS), 0, stream, p, q);
+    return hipGetLastError();
+}
+
+bool lass_dec6_fused_bf16_supported(const ConvArgs& p, const ConvArgs& q) {
+    return p.Cin == 64 && p.N == 32 && p.Nw == 32 && q.Cin == 32 && q.N == 32 && q.Nw == 32 && q.Cin2 == 64 && p.W % FPW == 0 &&
+           p.W >= FPW && p.in_bf16 && !p.in_bf16_lo && p.w_bf16 && q.w_bf16 && !p.w_bf16_lo && !q.w_bf16_lo && p.epi_scale &&
+           p.epi_shift && q.in2_bf16 && q.w2_bf16 && !q.w2_bf16_lo && q.bias && q.mask_re && q.mask_im && q.mask_w && q.mask_b &&
+           q.mask_mag && q.mask_cos && q.mask_sin && q.W + 1 == q.mask_nbins && q.mask_T > 0 && q.mask_T <= q.H && !q.pool_out &&
+           !q.pool_bf16 && q.H == p.H && q.W == p.W && q.B == p.B && (unsigned long long)p.H * p.W * 8ull < 0x10000000ull;
+}
+
+hipError_t lass_launch_dec6_fused_bf16(const ConvArgs& p, const ConvArgs& q, hipStream_t stream) {
+    if (!lass_dec6_fused_bf16_supported(p, q)) return hipErrorInvalidValue;
+    const long nblk = (long)(p.W / FPW) * ((p.H + FPHT - 1) / FPHT) * p.B;
+    hipLaunchKernelGGL(dec6_fused_bf16_kernel, dim3((unsigned)nblk), dim3(NTHREADS), 0, stream, p, q);
     return hipGetLastError();
 }

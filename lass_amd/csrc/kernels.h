@@ -118,6 +118,9 @@ hipError_t lass_launch_weights_bf16(const float* w, int Cout, int Cin, int taps,
 // p = the block's CONV1_ACT_PRE arguments, q = its CONV2_IDENT_PRE arguments with blocked bf16 outputs
 bool lass_enc1_fused_bf16_supported(const ConvArgs& p, const ConvArgs& q);
 hipError_t lass_launch_enc1_fused_bf16(const ConvArgs& p, const ConvArgs& q, hipStream_t stream);
+// ... and decoder_block6's (conv1 64 -> 32 from the activated cat copy, conv2 + 1x1 shortcut over the raw copy + output head)
+bool lass_dec6_fused_bf16_supported(const ConvArgs& p, const ConvArgs& q);
+hipError_t lass_launch_dec6_fused_bf16(const ConvArgs& p, const ConvArgs& q, hipStream_t stream);
 
 // ---- stft.hip -----------------------------------------------------------------------------------------------------
 // Multi-resolution analysis (scripts/precompute_stfts.py:19-58,573-590): nwin centred STFTs (n_fft = win in {256, 512,
