@@ -20,6 +20,13 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
+// Tile index of this workgroup: workgroup g runs on XCD g % 8 (its own L2); every XCD walks ONE contiguous range of tiles,
+// so the tiles that share halo rows / columns run side by side under the same L2 (as block_coords, wino_common.h).
+__device__ __forceinline__ unsigned fused_tile_index() {
+    const unsigned lin = blockIdx.x;
+    return (gridDim.x & 7u) == 0 ? (lin & 7u) * (gridDim.x >> 3) + (lin >> 3) : lin;
+}
+
 constexpr int FPW = 32, FPHT = 8;                           // output tile: 8 rows x 32 columns, 4 waves x 2 rows
 constexpr int IRI = FPHT + 4, IPI = FPW + 4, NPI = IRI * IPI;  // input image (halo 2): 12 x 36 pixels
 constexpr int IRM = FPHT + 2, IPM = FPW + 2, NPM = IRM * IPM;  // conv1 output = conv2 input (halo 1): 10 x 34 pixels
@@ -29,7 +36,7 @@ constexpr int IMG1_U4 = 2 * NPI, MID_U4 = 4 * NPM + 64;        // (+ slack: lane
 
 // p: conv1 of the block (CONV1_ACT_PRE arguments: x0, pre_w / pre_b, prologue and epilogue tables, w_bf16);
 // q: conv2 (CONV2_IDENT_PRE arguments with blocked bf16 outputs: res = x0, out_bf16 (+ _act), pool_bf16 (+ _act), w_bf16).
-__global__ __launch_bounds__(NTHREADS) void enc1_fused_bf16_kernel(ConvArgs p, ConvArgs q) {
+__global__ __launch_bounds__(NTHREADS, 3) void enc1_fused_bf16_kernel(ConvArgs p, ConvArgs q) {
     // conv2's weights (2 chunks) take over the input image + conv1 weight regions once conv1 is done: 47 KB per workgroup,
     // three workgroups per CU
     static_assert(2 * W_U4 <= IMG1_U4 + W_U4, "conv2's weights must fit the regions conv1 leaves behind");
@@ -47,8 +54,9 @@ __global__ __launch_bounds__(NTHREADS) void enc1_fused_bf16_kernel(ConvArgs p, C
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int khalf = lane >> 5, j = lane & 31;
     const int tiles_x = p.W / FPW;
-    const int bz = blockIdx.x / ((unsigned)tiles_x * ((p.H + FPHT - 1) / FPHT));
-    const int bxy = blockIdx.x - bz * tiles_x * ((p.H + FPHT - 1) / FPHT);
+    const unsigned tile = fused_tile_index();
+    const int bz = tile / ((unsigned)tiles_x * ((p.H + FPHT - 1) / FPHT));
+    const int bxy = tile - bz * tiles_x * ((p.H + FPHT - 1) / FPHT);
     const int y0 = (bxy / tiles_x) * FPHT, x0 = (bxy % tiles_x) * FPW;
     const int b = bz;
     const int HW = p.H * p.W;
@@ -226,16 +234,16 @@ __global__ __launch_bounds__(NTHREADS) void enc1_fused_bf16_kernel(ConvArgs p, C
 // The 32-channel intermediate (0.54 GB written and read back with its halo per step) never leaves the CU.
 // p: conv1 (CONV1_ACT arguments in the blocked pipeline: in_bf16 = activated cat copy, w_bf16, epilogue tables);
 // q: conv2 (CONV2_SHORTCUT arguments: w_bf16, in2_bf16 = raw cat copy, w2_bf16, bias, mask head).
-__global__ __launch_bounds__(NTHREADS) void dec6_fused_bf16_kernel(ConvArgs p, ConvArgs q) {
+__global__ __launch_bounds__(NTHREADS, 3) void dec6_fused_bf16_kernel(ConvArgs p, ConvArgs q) {
     // conv1's image and weight chunk are double-buffered (one barrier per chunk, the next chunk's units and weights arrive
-    // behind this chunk's MFMAs); conv2's weights (2 chunks) take over their regions once conv1 is done: 70 KB per workgroup,
-    // two workgroups per CU
+    // behind this chunk's MFMAs).  Once conv1 is done conv2's weights (2 chunks) take over buffer 0 and the intermediate
+    // image buffer 1: 47 KB per workgroup, three workgroups per CU (launch bounds: 168 registers)
     constexpr int BUF_U4 = IMG1_U4 + W_U4;  // one (image, weights) buffer
-    static_assert(2 * W_U4 <= 2 * BUF_U4, "conv2's weights must fit the regions conv1 leaves behind");
-    __shared__ uint4 lds4[2 * BUF_U4 + MID_U4 + (64 + 100 + 28) / 4];
-    uint4* mid = lds4 + 2 * BUF_U4;
+    static_assert(2 * W_U4 <= BUF_U4 && MID_U4 <= BUF_U4, "conv2's weights / the intermediate must fit one buffer each");
+    __shared__ uint4 lds4[2 * BUF_U4 + (64 + 100 + 28) / 4];
+    uint4* mid = lds4 + BUF_U4;
     uint4* w2 = lds4;
-    float* tabs = reinterpret_cast<float*>(mid + MID_U4);
+    float* tabs = reinterpret_cast<float*>(lds4 + 2 * BUF_U4);
     float* lds_es = tabs;        // conv1 epilogue (bn2 + FiLM) scale / shift
     float* lds_eh = tabs + 32;
     float* lds_mw = tabs + 64;   // after_conv weight [3][32] + bias [3]
@@ -244,8 +252,9 @@ __global__ __launch_bounds__(NTHREADS) void dec6_fused_bf16_kernel(ConvArgs p, C
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int khalf = lane >> 5, j = lane & 31;
     const int tiles_x = p.W / FPW, tiles = tiles_x * ((p.H + FPHT - 1) / FPHT);
-    const int b = blockIdx.x / (unsigned)tiles;
-    const int bxy = blockIdx.x - b * tiles;
+    const unsigned tile = fused_tile_index();
+    const int b = tile / (unsigned)tiles;
+    const int bxy = tile - b * tiles;
     const int y0 = (bxy / tiles_x) * FPHT, x0 = (bxy % tiles_x) * FPW;
     const int HW = p.H * p.W;
 
@@ -348,6 +357,7 @@ __global__ __launch_bounds__(NTHREADS) void dec6_fused_bf16_kernel(ConvArgs p, C
         }
     }
 
+    __syncthreads();  // every wave is done with image buffer 1 (chunk 3): the intermediate image goes there
     // ---- shortcut operands (1x1 over the raw cat copy, resunet.py:163): requested here (they arrive behind the epilogue below), contracted behind conv2 -------------
     const uint4* raw = reinterpret_cast<const uint4*>(q.in2_bf16) + (size_t)b * (q.Cin2 / 8) * HW;
     const uint4* wsc = reinterpret_cast<const uint4*>(q.w2_bf16);  // [chunk][octet][cout]

@@ -13,7 +13,7 @@ import sys
 sys.path.insert(0, '.')
 from lass_amd import arch
 
-CONV = re.compile(r'wino32_kernel|wino_kernel|conv_kernel|conv_bf16_kernel|enc1_fused_bf16_kernel')
+CONV = re.compile(r'wino32_kernel|wino_kernel|conv_kernel|conv_bf16_kernel|fused_bf16_kernel')
 
 
 def load(path):

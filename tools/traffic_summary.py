@@ -28,7 +28,7 @@ def per_dispatch(path, counter):
 
 
 def is_conv3x3(name):
-    if 'wino_kernel' in name or 'wino32_kernel' in name or 'enc1_fused_bf16_kernel' in name:
+    if 'wino_kernel' in name or 'wino32_kernel' in name or 'fused_bf16_kernel' in name:
         return True
     if 'conv_bf16_kernel<9' in name or 'conv_bf16_kernelILi9E' in name:
         return True
@@ -52,8 +52,8 @@ def main(fetch_csv, write_csv, out_json, dtype, calib_json=None):
         ratio_f, ratio_w = sum(rf) / len(rf), sum(rw) / len(rw)
     f = [e for e in last_step(per_dispatch(fetch_csv, 'FETCH_SIZE')) if is_conv3x3(e['name'])]
     w = [e for e in last_step(per_dispatch(write_csv, 'WRITE_SIZE')) if is_conv3x3(e['name'])]
-    launches_per_step = len(f)  # 26 (f32, bf16x3) or 25 (bf16: encoder_block1 is one kernel)
-    assert launches_per_step in (25, 26) and len(w) == launches_per_step, (len(f), len(w))
+    launches_per_step = len(f)  # 26 (f32, bf16x3) or 24 (bf16: encoder_block1 and decoder_block6 are one kernel each)
+    assert launches_per_step in (24, 25, 26) and len(w) == launches_per_step, (len(f), len(w))
     fetch = sum(e['v'] for e in f) * 1024.0 / ratio_f
     write = sum(e['v'] for e in w) * 1024.0 / ratio_w
     res = {
