@@ -504,7 +504,7 @@ def test_bf16_mode_convblock_and_waveform(synthetic_sd, oracle_sd, monkeypatch):
         {"mixture": torch.from_numpy(mix)[:, None, :].to(DEV), "condition": torch.from_numpy(c2).to(DEV)})["waveform"]
     monkeypatch.delenv("LASS_FUSE_CATB")
     assert _relerr(out2, out) < 1e-5
-    # encoder_block1 as ONE kernel (conv_bf16_fused.hip: its 32-channel intermediate stays in LDS) is the default; the
+    # encoder_block1 and decoder_block6 as ONE kernel each (conv_bf16_fused.hip: the 32-channel intermediate stays in LDS) is the default; the
     # two-launch form rounds the same f32 accumulators to the same bf16 intermediate: same waveform
     monkeypatch.setenv("LASS_FUSE_BLOCK", "0")
     m3 = ResUNet30(1, 1, 512)
@@ -512,7 +512,7 @@ def test_bf16_mode_convblock_and_waveform(synthetic_sd, oracle_sd, monkeypatch):
     out3 = m3.to(DEV).eval().set_compute_dtype("bf16")(
         {"mixture": torch.from_numpy(mix)[:, None, :].to(DEV), "condition": torch.from_numpy(c2).to(DEV)})["waveform"]
     monkeypatch.delenv("LASS_FUSE_BLOCK")
-    print("fused vs two-launch encoder_block1 (bf16): relative RMS difference", _relerr(out3, out))
+    print("fused vs two-launch encoder_block1 / decoder_block6 (bf16): relative RMS difference", _relerr(out3, out))
     assert _relerr(out3, out) < 1e-5
 
 
