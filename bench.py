@@ -444,7 +444,8 @@ def main():
         alg_bytes_launch = alg_bytes_launch_of(head)
         kernel = {"f32": "wino_kernel<...> x19 + wino32_kernel<...> x7: 3x3 convs as Winograd F(2x2,3x3) on v_mfma_f32_16x16x4_f32 + fused 1x1 "
                          "shortcuts (conv3x3_mfma class)" if wino else "conv_kernel (direct f32 MFMA)",
-                  "bf16": "conv_bf16_kernel x26: direct 3x3 + fused 1x1 shortcuts on v_mfma_f32_32x32x16_bf16",
+                  "bf16": "conv_bf16_kernel x22 + enc1_fused / dec6_fused_bf16_kernel (a ConvBlockRes each): direct 3x3 + fused 1x1 "
+                          "shortcuts on v_mfma_f32_32x32x16_bf16",
                   "bf16x3": "conv_bf16_kernel (split operands, 3 MFMAs per product) x26"}[args.dtype]
         res = {
             "metric": "clips/sec (10s@16kHz)", "value": world * B * args.steps / dt, "unit": "clips/s",
