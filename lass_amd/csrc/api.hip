@@ -109,6 +109,8 @@ struct lass_ctx {
     bool fuse_pool = true;  // LASS_FUSE_POOL=0 selects the stand-alone pool kernel (A/B + parity of both paths)
     bool fuse_catb = true;  // bf16 mode: decoder concats as blocked bf16 copies (LASS_FUSE_CATB=0: f32 concat)
     bool fuse_block = true;  // bf16 mode: encoder_block1 as one kernel, intermediate in LDS (LASS_FUSE_BLOCK=0: two launches)
+    bool fuse_up = true;    // bf16 mode: decoder_block6's transposed conv inside its fused kernel (LASS_FUSE_UP=0: its own launch)
+    void* up_sc16 = nullptr;  // ... the 1x1 shortcut composed with that transposed conv, bf16 [4][2][128] units (lass_finalize)
     bool fuse_mask = true;  // LASS_FUSE_MASK=0 keeps after_conv + mask as their own kernel behind decoder_block6
     // hipGraph replay of lass_separate (LASS_GRAPH=0 disables): the ~40 launches of one (pointers, shape) combination are
     // captured once on an internal stream and replayed on the caller's stream
@@ -397,11 +399,19 @@ struct PreConv {
     const float* b;
 };
 
+// bf16 mode, decoder_block6: the transposed conv in front of the block runs inside the fused kernel (conv_bf16_fused.hip)
+struct UpFuse {
+    const void* x_act;   // previous decoder's output, that conv's prologue applied, blocked bf16 (B, cin/8, h, w, 8)
+    int cin, h, w;
+    const void* w16;     // transposed-conv weights, bf16
+    const void* wsc16;   // shortcut (up-sampled half) composed with the transposed conv, bf16
+};
+
 int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int B, int H, int W, const float* shift,
                  float* a2, float* out, long out_bs, hipStream_t st, float* pool_out = nullptr, int pool_h = 2,
                  const PreConv* pre = nullptr, const MaskHead* mh = nullptr, const CatCopies* skip_out = nullptr,
                  const CatCopies* cat_in = nullptr, const Site* act_out = nullptr, const CatCopies* pool_copies = nullptr,
-                 long pool_bs = 0) {
+                 long pool_bs = 0, const UpFuse* up = nullptr) {
     const float* x0 = pre ? pre->x0 : nullptr;
     const Site& s1 = c->sites[rb.s1];
     const Site& s2 = c->sites[rb.s2];
@@ -492,6 +502,17 @@ int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int
     if (rb.cin != rb.cout) { q.in2 = x; q.in2_bs = x_bs; q.Cin2 = rb.cin; q.w2 = rb.wsc; q.bias = rb.bsc; }
     // ... and decoder_block6's ConvBlockRes with the output head behind it (conv1 from the activated cat copy, the 1x1
     // shortcut from the raw one)
+    if (up) {  // the caller has NOT run the transposed conv: only the kernel that contains it will do
+        ConvArgs uq;
+        uq.in_bf16 = up->x_act; uq.Cin = up->cin; uq.H = up->h; uq.W = up->w; uq.B = B;
+        uq.w_bf16 = up->w16; uq.w2_bf16 = up->wsc16;
+        if (!(bf2 && !x0 && c->fuse_block && c->compute_mode == LASS_COMPUTE_BF16 && cat_in && mh && rb.cin != rb.cout &&
+              lass_dec6u_fused_bf16_supported(p, q, uq)))
+            return fail(c, LASS_ERR_STATE, "decoder_block6 with its transposed conv inside needs the fused bf16 kernel");
+        ProfScope ps(c, st, P_CONV3X3);
+        HIP_TRY(c, lass_launch_dec6u_fused_bf16(p, q, uq, st));
+        return 0;
+    }
     if (bf2 && !x0 && c->fuse_block && c->compute_mode == LASS_COMPUTE_BF16 && cat_in && mh && rb.cin != rb.cout &&
         lass_dec6_fused_bf16_supported(p, q)) {
         ProfScope ps(c, st, P_CONV3X3);
@@ -680,6 +701,7 @@ static int create_impl(lass_ctx** out, int device_id, const Geometry& geom) {
     if (const char* e = getenv("LASS_FUSE_MASK")) c->fuse_mask = atoi(e) != 0;
     if (const char* e = getenv("LASS_FUSE_CATB")) c->fuse_catb = atoi(e) != 0;
     if (const char* e = getenv("LASS_FUSE_BLOCK")) c->fuse_block = atoi(e) != 0;
+    if (const char* e = getenv("LASS_FUSE_UP")) c->fuse_up = atoi(e) != 0;
     if (const char* e = getenv("LASS_FUSE_PRECONV")) c->fuse_preconv = atoi(e) != 0;
     if (const char* e = getenv("LASS_GRAPH")) c->use_graph = atoi(e) != 0;
     c->prof.resize(P_COUNT);
@@ -919,6 +941,24 @@ int lass_finalize(lass_ctx* c, int compute_mode) {
                 HIP_TRY(c, lass_launch_weights_bf16(wu, N, d.cin, 1, l, 1, 1, st));
                 c->up16l[i] = l;
             }
+        }
+    }
+    // decoder_block6's shortcut over the up-sampled half of its concat, composed with the transposed conv (dec6u_fused_bf16_kernel)
+    c->up_sc16 = nullptr;
+    {
+        const DecSpec& d = c->D[5];
+        const ResBlock& rb = c->dec[5];
+        if (c->compute_mode == LASS_COMPUTE_BF16 && c->g.variant == 0 && d.cin == 64 && d.cout == 32 && d.uh == 2 && d.uw == 2 &&
+            rb.cin == 64 && rb.cout == 32 && c->up16[5]) {
+            const float* wu = need(std::string("base.") + d.name + ".conv1.weight");
+            const float* ws = need(rb.prefix + ".shortcut.weight");
+            if (!wu || !ws) return LASS_ERR_STATE;
+            float* tmp = nullptr;
+            unsigned short* t16 = nullptr;
+            if (dev_alloc(c, &tmp, (size_t)4 * rb.cout * d.cin) || dev_alloc(c, &t16, (size_t)4 * rb.cout * d.cin)) return LASS_ERR_HIP;
+            HIP_TRY(c, lass_launch_compose_up_shortcut(ws, wu, d.cin, d.cout, rb.cin, rb.cout, tmp, st));
+            HIP_TRY(c, lass_launch_weights_bf16(tmp, 4 * rb.cout, d.cin, 1, t16, 0, 0, st));
+            c->up_sc16 = t16;
         }
     }
     HIP_TRY(c, hipStreamSynchronize(st));
@@ -1309,8 +1349,16 @@ static int separate_impl(lass_ctx* c, const float* mixture, const Components* co
         const long HW = (long)H * W;
         const int h = H / c->D[d].uh, w = W / c->D[d].uw;
         const ResBlock& rb = c->dec[d];
-        r = run_upconv(c, d, x, B, h, w, shift, F(pl.cat[d]), rb.cin * HW, st, use_cb[d] ? &cb[d] : nullptr, x_act);
-        if (r) return r;
+        // decoder_block6 in the blocked bf16 pipeline: the transposed conv runs inside the block's fused kernel, its output
+        // (half of the concat, at the full resolution) is never written
+        const UpFuse upf{x, c->D[d].cin, h, w, c->up16[d], c->up_sc16};
+        const bool fuse_up = d == 5 && c->fuse_up && c->fuse_block && c->fuse_mask && use_cb[d] && x_act && c->up_sc16 &&
+                             c->compute_mode == LASS_COMPUTE_BF16 && rb.cout == 32 && rb.cin == 64 && W == g.fcrop && W % 32 == 0 &&
+                             H % 2 == 0 && (unsigned long long)H * W * 8ull < 0x10000000ull;
+        if (!fuse_up) {
+            r = run_upconv(c, d, x, B, h, w, shift, F(pl.cat[d]), rb.cin * HW, st, use_cb[d] ? &cb[d] : nullptr, x_act);
+            if (r) return r;
+        }
         // this decoder's output feeds only the next transposed conv: hand it over activated, as blocked bf16
         const bool act_next = g.variant == 0 && d < 5 && c->fuse_catb && c->compute_mode == LASS_COMPUTE_BF16 && rb.b1 && rb.b2 &&
                               rb.bsc16 && rb.cout % 16 == 0 && c->up16[d + 1];
@@ -1320,7 +1368,7 @@ static int separate_impl(lass_ctx* c, const float* mixture, const Components* co
         fused_head = d == 5 && c->fuse_mask && rb.cout == 32 && rb.cin != rb.cout && W == g.fcrop;
         r = run_resblock(c, rb, F(pl.cat[d]), rb.cin * HW, B, H, W, shift, F(pl.a2), F(pl.decout[d]), rb.cout * HW, st,
                          nullptr, 2, nullptr, fused_head ? &head : nullptr, nullptr, use_cb[d] ? &cb[d] : nullptr,
-                         act_next ? &c->sites[c->dec_site[d + 1]] : nullptr);
+                         act_next ? &c->sites[c->dec_site[d + 1]] : nullptr, nullptr, 0, fuse_up ? &upf : nullptr);
         if (r) return r;
         x = F(pl.decout[d]);
     }

@@ -434,6 +434,345 @@ __global__ __launch_bounds__(NTHREADS, 3) void dec6_fused_bf16_kernel(ConvArgs p
     store_tile<1, 2, FPW, F_MASK, false>(q, acc2, nullptr, nullptr, nullptr, b, 0, y0, x0, lane, wave, lds_mw, nullptr);
 }
 
+
+// ---- decoder_block6 with its transposed conv INSIDE (resunet.py:240-264 at the shape of :408-418) --------------------------
+// The up-sampled half of the concat (32 channels at the full resolution: 1.1 GB written as two copies and read back with its
+// halo per step) never exists in HBM.  A workgroup forms it for its own 12 x 36 input tile from the 6 x 18 low-resolution
+// pixels underneath: kernel = stride, so ConvTranspose2d is a pointwise GEMM  up[(co, a, bb)][pixel] = sum_ci Wt[ci][(co, a, bb)]
+// x[ci][pixel]  (x = decoder_block5's output with this conv's BN+FiLM+leaky already applied, blocked bf16) - 16 MFMAs per wave
+// with BOTH operands straight from global memory (a lane's fragment is one 16-byte unit of either).  An accumulator tile is one
+// channel octet x 4 sub-pixels; the khalf pair swaps halves (as tconv_store), applies conv_block2.bn1 + FiLM + leaky and writes
+// 16-byte units into the image buffers of conv1's chunks 0 and 1; chunks 2 and 3 (the encoder skip) come from the activated cat
+// copy as before.
+// The 1x1 shortcut over the up-sampled half is linear in x as well:  Wsc[:, :32] up = W' x  with the composed weights
+// W'[(a, bb, n)][ci] = sum_co Wsc[n][co] Wt[ci][(co, a, bb)]  (lass_finalize, f32 products rounded to bf16 once).  Its
+// accumulator tile for sub-pixel (a, bb) is [32 couts][low-res pixels], so conv2 runs in THAT layout: wave w owns sub-pixel
+// class (a, bb) = (w >> 1, w & 1) of the 8 x 32 output tile, column tile t, lane j = low-res pixel (2t + (j >> 4), j & 15); the
+// intermediate image is kept parity-split ([row][column parity][20]) so that a wave's B fragments are contiguous 16-byte units.
+// p, q: as dec6_fused_bf16_kernel (p.pro_scale / pro_shift = conv_block2.bn1 of the concat channels);  u: the transposed conv
+// (in_bf16 = x, w_bf16 = Wt [4][2][128] units, w2_bf16 = W' [4][2][128] units, H x W = the low resolution).
+constexpr int LRI = IRI / 2, LPI = IPI / 2, NLP = LRI * LPI;  // low-resolution halo tile: 6 x 18 = 108 pixels
+constexpr int MPH = 20, MPITCH = 2 * MPH;                      // parity-split intermediate row (17 of 20 units used per parity;
+                                                               // two rows = 80 units = 0 mod 16: lanes 16-31 fall on the banks behind lanes 0-15)
+constexpr int MROWS_U4 = IRM * MPITCH, MIDP_U4 = 4 * MROWS_U4;
+
+__global__ __launch_bounds__(NTHREADS, 3) void dec6u_fused_bf16_kernel(ConvArgs p, ConvArgs q, ConvArgs u) {
+    constexpr int BUF_U4 = IMG1_U4 + W_U4;  // one (image, weights) buffer
+    static_assert(2 * W_U4 + MIDP_U4 <= 2 * BUF_U4 && 2 * W_U4 <= BUF_U4, "conv2's weights fit buffer 0; the intermediate starts behind them");
+    __shared__ uint4 lds4[2 * BUF_U4 + 57];
+    uint4* mid = lds4 + 2 * W_U4;  // behind conv2's weights; written only after conv1's last chunk
+    uint4* w2 = lds4;
+    float* tabs = reinterpret_cast<float*>(lds4 + 2 * BUF_U4);
+    float* lds_es = tabs;        // conv1 epilogue (bn2 + FiLM) scale / shift
+    float* lds_eh = tabs + 32;
+    float* lds_mw = tabs + 64;   // after_conv weight [3][32] + bias [3]
+    float* lds_us = tabs + 164;  // conv_block2.bn1 + FiLM of the up-sampled channels (concat channels 0..31)
+    float* lds_uh = tabs + 196;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int khalf = lane >> 5, j = lane & 31;
+    const int tiles_x = p.W / FPW, tiles = tiles_x * ((p.H + FPHT - 1) / FPHT);
+    const unsigned tile = fused_tile_index();
+    const int b = tile / (unsigned)tiles;
+    const int bxy = tile - b * tiles;
+    const int y0 = (bxy / tiles_x) * FPHT, x0 = (bxy % tiles_x) * FPW;
+    const int HW = p.H * p.W;
+    const int lh = u.H, lw = u.W, lhw = lh * lw;
+
+    if (tid < 32) {
+        lds_es[tid] = p.epi_scale[tid];
+        lds_eh[tid] = p.epi_shift[(size_t)b * p.epi_shift_bs + tid];
+        lds_us[tid] = p.pro_scale[tid];
+        lds_uh[tid] = p.pro_shift[(size_t)b * p.pro_shift_bs + tid];
+    }
+    if (tid < 99) lds_mw[tid] = tid < 96 ? q.mask_w[tid] : q.mask_b[tid - 96];
+
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) uint4*)lds4;
+    const v4i32 w1_rs = make_rsrc_words(p.w_bf16, 4u * W_U4 * 16u);
+    const v4i32 w2_rs = make_rsrc_words(q.w_bf16, 2u * W_U4 * 16u);
+    constexpr int NCH = 4;  // 64 concat channels
+    auto dma_w1 = [&](int c) {  // conv1's weight chunk c -> buffer c & 1
+        for (int piece = wave; piece < W_U4 / 64; piece += 4)
+            lds_dma_16B(w1_rs, (unsigned)lane * 16u, (unsigned)((c * W_U4 + piece * 64) * 16),
+                        lds0 + (unsigned)(((c & 1) * BUF_U4 + IMG1_U4 + piece * 64) * 16));
+    };
+    dma_w1(0);
+    dma_w1(1);
+
+    // ---- phase 0: the transposed conv of this tile's 6 x 18 low-resolution pixels -> conv1's image chunks 0 and 1 ------------
+    const uint4* xa = reinterpret_cast<const uint4*>(u.in_bf16) + (size_t)b * (u.Cin / 8) * lhw;
+    const uint4* wt = reinterpret_cast<const uint4*>(u.w_bf16);
+    const int qpx = wave * 32 + j;  // this lane's low-resolution pixel (MFMA column) in the 6 x 18 tile
+    const bool qvalid = qpx < NLP;
+    const int qq = qvalid ? qpx : NLP - 1;
+    const int ly = qq / LPI, lx = qq - ly * LPI;
+    const int gly = (y0 >> 1) - 1 + ly, glx = (x0 >> 1) - 1 + lx;
+    const bool qin = qvalid && gly >= 0 && gly < lh && glx >= 0 && glx < lw;  // outside the image: conv1's zero padding
+    const unsigned xoff = (unsigned)(min(max(gly, 0), lh - 1) * lw + min(max(glx, 0), lw - 1));
+    // every operand of the 16 MFMAs is requested up front (80 registers, free at this point of the kernel): one exposed
+    // round trip instead of one per accumulator tile (hipcc sinks the loads to their uses otherwise)
+    uint4 xb[4], wa[4][4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) xb[s] = xa[(size_t)(2 * s + khalf) * lhw + xoff];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) wa[m][s] = wt[(s * 2 + khalf) * 128 + 32 * m + j];
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();  // tables visible
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {  // accumulator tile m = concat channels 8m .. 8m+7 x 4 sub-pixels
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wa[m][s]), __builtin_bit_cast(bf16x8, xb[s]), acc, 0, 0, 0);
+        // register r = row (r & 3) + 8 (r >> 2) + 4 khalf = channel 2 (r >> 2) + khalf, sub-pixel r & 3 = (a, bb).  One
+        // v_permlane32_swap per (channel pair, bb) hands lane khalf output row a = khalf with all 8 channels (two adjacent
+        // units, bb = 0, 1): it swaps lanes 32-63 of its first operand (a = 0 values of the odd channel) with lanes 0-31 of
+        // the second (a = 1 values of the even channel)
+        float ch[2][8];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+                const float a0 = acc[4 * g + bb], a1 = acc[4 * g + 2 + bb];  // (named floats: hipcc's bit_cast of a vector ELEMENT reads element 0)
+                const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a0), __builtin_bit_cast(unsigned, a1), false, false);
+                const unsigned r0 = sw[0], r1 = sw[1];
+                ch[bb][2 * g] = __builtin_bit_cast(float, r0);
+                ch[bb][2 * g + 1] = __builtin_bit_cast(float, r1);
+            }
+        float us[8], uh[8];
+        {
+            const float4 a0 = *reinterpret_cast<const float4*>(lds_us + 8 * m), a1 = *reinterpret_cast<const float4*>(lds_us + 8 * m + 4);
+            const float4 h0 = *reinterpret_cast<const float4*>(lds_uh + 8 * m), h1 = *reinterpret_cast<const float4*>(lds_uh + 8 * m + 4);
+            us[0] = a0.x; us[1] = a0.y; us[2] = a0.z; us[3] = a0.w; us[4] = a1.x; us[5] = a1.y; us[6] = a1.z; us[7] = a1.w;
+            uh[0] = h0.x; uh[1] = h0.y; uh[2] = h0.z; uh[3] = h0.w; uh[4] = h1.x; uh[5] = h1.y; uh[6] = h1.z; uh[7] = h1.w;
+        }
+        uint4* img = lds4 + (m >> 1) * BUF_U4 + (m & 1) * NPI + (2 * ly + khalf) * IPI + 2 * lx;
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb) {
+            bf16x8 v;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float t = leaky(ch[bb][k] * us[k] + uh[k]);  // conv_block2.bn1 + FiLM + leaky (resunet.py:150)
+                v[k] = (__bf16)(qin ? t : 0.f);
+            }
+            if (qvalid) *reinterpret_cast<bf16x8*>(img + bb) = v;
+        }
+    }
+
+    // ---- the encoder skip (concat channels 32..63 = chunks 2, 3): this thread's units of the 12 x 36 tile, staged in registers
+    const uint4* act = reinterpret_cast<const uint4*>(p.in_bf16) + (size_t)b * (p.Cin / 8) * HW;
+    unsigned uoff[NPPI], okbits = 0;
+#pragma unroll
+    for (int k = 0; k < NPPI; ++k) {
+        const int un = min(tid + k * NTHREADS, NPI - 1);
+        const int gy = y0 + un / IPI - 2, gx = x0 + un % IPI - 2;
+        const bool ok = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        uoff[k] = (unsigned)(min(max(gy, 0), p.H - 1) * p.W + min(max(gx, 0), p.W - 1));
+        okbits |= (ok ? 1u : 0u) << k;
+    }
+    uint4 stage[2][2][NPPI];  // chunk c in set c & 1
+    auto load_chunk = [&](int c) {
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int k = 0; k < NPPI; ++k) stage[c & 1][o][k] = act[(size_t)(2 * c + o) * HW + uoff[k]];
+    };
+    auto put_chunk = [&](int c) {  // the staged units of chunk c -> image buffer c & 1 (conv zero padding applied here)
+        uint4* img = lds4 + (c & 1) * BUF_U4;
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int k = 0; k < NPPI; ++k) {
+                const int un = tid + k * NTHREADS;
+                const bool ok = (okbits >> k) & 1u;
+                if (un < NPI) img[o * NPI + un] = ok ? stage[c & 1][o][k] : uint4{0u, 0u, 0u, 0u};
+            }
+    };
+    load_chunk(2);
+    load_chunk(3);
+
+    int mir[3], mic[3];  // conv1's pixel tiles: as in enc1_fused_bf16_kernel
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        int ir = wave + 4 * s, ic = 1 + j;
+        if (s == 2 && wave >= 2) {
+            ir = wave == 2 ? (j >> 1) : IRM;  // wave 3: nothing
+            ic = (j & 1) ? IPM - 1 : 0;
+        }
+        mir[s] = ir;
+        mic[s] = ic;
+    }
+    f32x16 acc1[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[s][r] = 0.f;
+
+    // conv2 / shortcut pixel classes (see the header): sub-pixel (spa, spb) = wave, column tile t, lane j
+    const int spa = wave >> 1, spb = wave & 1;
+    int oy[2];
+    const int ox = 2 * (j & 15) + spb;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) oy[t] = 2 * (2 * t + (j >> 4)) + spa;
+    uint4 xs[2][4], au[4];  // shortcut over the up-sampled half: W' (rows of this wave's sub-pixel) and x at the inner 4 x 16 pixels
+
+    wait_vmcnt<2 * 2 * NPPI>();  // conv1's weight chunks 0 and 1 have landed (only the skip units are younger)
+    __syncthreads();             // ... and everyone's image units of chunks 0 and 1 are written
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        if (c >= 1 && c + 1 < NCH) dma_w1(c + 1);  // its buffer was last read in chunk c-1: every wave is past that (barrier below)
+        if (c == NCH - 1) {              // buffer 0 is free for good: conv2's weights move in behind the last chunk's MFMAs
+            for (int piece = wave; piece < 2 * W_U4 / 64; piece += 4)
+                lds_dma_16B(w2_rs, (unsigned)lane * 16u, (unsigned)piece * 1024u, lds0 + (unsigned)(piece * 1024));
+            const uint4* wsu = reinterpret_cast<const uint4*>(u.w2_bf16);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                au[s] = wsu[(s * 2 + khalf) * 128 + wave * 32 + j];
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    xs[t][s] = xa[(size_t)(2 * s + khalf) * lhw + (size_t)min((y0 >> 1) + 2 * t + (j >> 4), lh - 1) * lw + (x0 >> 1) + (j & 15)];
+            }
+        }
+        const uint4* img = lds4 + (c & 1) * BUF_U4;
+        const bf16x8* abase = reinterpret_cast<const bf16x8*>(img + IMG1_U4) + khalf * 32 + j;
+        const bf16x8* ibase = reinterpret_cast<const bf16x8*>(img) + khalf * NPI;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const bf16x8 a = abase[tap * 64];
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int ir = min(mir[s], IRM - 1);
+                const bf16x8 bb = ibase[(ir + tap / 3) * IPI + mic[s] + tap % 3];
+                acc1[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bb, acc1[s], 0, 0, 0);
+            }
+        }
+        if (c + 1 < NCH) {
+            if (c + 1 >= 2) put_chunk(c + 1);  // image buffer (c+1) & 1 was last read in chunk c-1
+            wait_vmcnt<0>();                   // this wave's weight pieces of chunk c+1
+            __syncthreads();
+        }
+    }
+    // accumulators of conv2 start at the shortcut's bias (resunet.py:163) + the shortcut over the up-sampled half
+    f32x16 acc2[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float bb = q.bias[(r & 3) + 8 * (r >> 2) + 4 * khalf];
+        acc2[0][r] = bb;
+        acc2[1][r] = bb;
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+            acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, au[s]), __builtin_bit_cast(bf16x8, xs[t][s]), acc2[t], 0, 0, 0);
+
+    __syncthreads();  // every wave is done with buffer 1 (chunk 3): the intermediate image goes there
+    // ---- shortcut over the skip half (1x1 over the RAW cat copy, resunet.py:163): requested here, contracted behind conv2 ------
+    const uint4* raw = reinterpret_cast<const uint4*>(q.in2_bf16) + (size_t)b * (q.Cin2 / 8) * HW;
+    const uint4* wsc = reinterpret_cast<const uint4*>(q.w2_bf16);  // [chunk][octet][cout]
+    uint4 sa[2], sb[2][2];
+#pragma unroll
+    for (int c = 2; c < NCH; ++c) {
+        sa[c - 2] = wsc[c * 64 + khalf * 32 + j];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+            sb[c - 2][t] = raw[(size_t)(2 * c + khalf) * HW + (size_t)min(y0 + oy[t], q.H - 1) * q.W + x0 + ox];
+    }
+    // ---- conv1 epilogue: bn2 + FiLM + leaky (resunet.py:151), zero outside the image, bf16 -> the intermediate image ------
+    {
+        float es4[4][4], eh4[4][4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 a = *reinterpret_cast<const float4*>(lds_es + 8 * g + 4 * khalf);
+            const float4 c = *reinterpret_cast<const float4*>(lds_eh + 8 * g + 4 * khalf);
+            es4[g][0] = a.x; es4[g][1] = a.y; es4[g][2] = a.z; es4[g][3] = a.w;
+            eh4[g][0] = c.x; eh4[g][1] = c.y; eh4[g][2] = c.z; eh4[g][3] = c.w;
+        }
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int ir = mir[s], ic = mic[s];
+            const int gy = y0 - 1 + ir, gx = x0 - 1 + ic;
+            const bool inside = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            if (ir < IRM) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    bf16x4 v;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float t = leaky(acc1[s][4 * g + i] * es4[g][i] + eh4[g][i]);
+                        v[i] = (__bf16)(inside ? t : 0.f);
+                    }
+                    *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(mid + g * MROWS_U4 + ir * MPITCH + (ic & 1) * MPH + (ic >> 1)) + khalf * 8) = v;
+                }
+            }
+        }
+    }
+    wait_vmcnt<0>();  // conv2's weights, the shortcut operands
+    __syncthreads();
+
+    // ---- conv2 over the intermediate image, sub-pixel class (spa, spb) ----------------------------------------------------------
+    int lbase[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) lbase[t] = 2 * (2 * t + (j >> 4)) * MPITCH + (j & 15);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const bf16x8* bbase = reinterpret_cast<const bf16x8*>(mid) + (2 * c + khalf) * MROWS_U4;
+        const bf16x8* abase = reinterpret_cast<const bf16x8*>(w2 + c * W_U4) + khalf * 32 + j;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const bf16x8 a = abase[tap * 64];
+            const int col = spb + tap % 3;  // intermediate column = 2 lx + col, row = 2 ly + spa + tap / 3
+            const int off = (spa + tap / 3) * MPITCH + (col & 1) * MPH + (col >> 1);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bbase[lbase[t] + off], acc2[t], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+            acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, sa[c]), __builtin_bit_cast(bf16x8, sb[c][t]), acc2[t], 0, 0, 0);
+
+    // ---- after_conv + complex ratio mask (resunet.py:570-574,436-519): the khalf pair holds all 32 channels of a pixel; lane
+    // khalf finishes the pixel of column tile t = khalf
+    float lg[3];
+#pragma unroll
+    for (int qd = 0; qd < 3; ++qd) {
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float wv = lds_mw[qd * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf];
+            s0 += wv * acc2[0][r];
+            s1 += wv * acc2[1][r];
+        }
+        s0 += __shfl_xor(s0, 32, 64);
+        s1 += __shfl_xor(s1, 32, 64);
+        lg[qd] = (khalf ? s1 : s0) + lds_mw[96 + qd];
+    }
+    const int yy = y0 + (khalf ? oy[1] : oy[0]);
+    if (yy < q.mask_T) mask_pixel(q, b, yy, x0 + ox, lg[0], lg[1], lg[2]);
+}
+
+
+// W'[(sp, n)][ci] = sum_co Wsc[n][co] * Wt[ci][co][sp]  (sp = a * 2 + bb): the 1x1 shortcut of decoder_block6's ConvBlockRes
+// composed with the transposed conv in front of it (both linear; resunet.py:122-128,163 and :216-224,250), f32.
+// wsc (Nsc, Ccat, 1, 1) - only its first Cup input channels (the up-sampled half of torch.cat((x, skip), 1)); wt (Cin, Cup, 2, 2).
+__global__ __launch_bounds__(256) void compose_up_shortcut_kernel(const float* __restrict__ wsc, const float* __restrict__ wt,
+                                                                  int Cin, int Cup, int Ccat, int Nsc, float* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;  // ((sp * Nsc) + n) * Cin + ci
+    if (i >= 4 * Nsc * Cin) return;
+    const int ci = i % Cin, n = (i / Cin) % Nsc, sp = i / (Cin * Nsc);
+    double s = 0.0;
+    for (int co = 0; co < Cup; ++co) s += (double)wsc[(size_t)n * Ccat + co] * (double)wt[((size_t)ci * Cup + co) * 4 + sp];
+    out[i] = (float)s;
+}
+
 }  // namespace
 
 bool lass_enc1_fused_bf16_supported(const ConvArgs& p, const ConvArgs& q) {
@@ -462,5 +801,24 @@ hipError_t lass_launch_dec6_fused_bf16(const ConvArgs& p, const ConvArgs& q, hip
     if (!lass_dec6_fused_bf16_supported(p, q)) return hipErrorInvalidValue;
     const long nblk = (long)(p.W / FPW) * ((p.H + FPHT - 1) / FPHT) * p.B;
     hipLaunchKernelGGL(dec6_fused_bf16_kernel, dim3((unsigned)nblk), dim3(NTHREADS), 0, stream, p, q);
+    return hipGetLastError();
+}
+
+bool lass_dec6u_fused_bf16_supported(const ConvArgs& p, const ConvArgs& q, const ConvArgs& u) {
+    return lass_dec6_fused_bf16_supported(p, q) && p.pro_scale && p.pro_shift && u.in_bf16 && u.w_bf16 && u.w2_bf16 && u.Cin == 64 &&
+           u.H * 2 == p.H && u.W * 2 == p.W && u.B == p.B && p.H % 2 == 0 && (unsigned long long)u.H * u.W * 8ull < 0x10000000ull;
+}
+
+hipError_t lass_launch_dec6u_fused_bf16(const ConvArgs& p, const ConvArgs& q, const ConvArgs& u, hipStream_t stream) {
+    if (!lass_dec6u_fused_bf16_supported(p, q, u)) return hipErrorInvalidValue;
+    const long nblk = (long)(p.W / FPW) * ((p.H + FPHT - 1) / FPHT) * p.B;
+    hipLaunchKernelGGL(dec6u_fused_bf16_kernel, dim3((unsigned)nblk), dim3(NTHREADS), 0, stream, p, q, u);
+    return hipGetLastError();
+}
+
+hipError_t lass_launch_compose_up_shortcut(const float* wsc, const float* wt, int Cin, int Cup, int Ccat, int Nsc, float* out,
+                                           hipStream_t stream) {
+    const int n = 4 * Nsc * Cin;
+    hipLaunchKernelGGL(compose_up_shortcut_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, wsc, wt, Cin, Cup, Ccat, Nsc, out);
     return hipGetLastError();
 }

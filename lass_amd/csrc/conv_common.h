@@ -25,6 +25,17 @@ constexpr int F_INBF16 = 512;   // bf16 kernels: phase A reads that intermediate
 
 constexpr int NTHREADS = 256;
 
+// The khalf pair of a pixel (lanes j, j + 32) holds the two 8-byte halves of every 16-byte unit of the blocked bf16 layout.
+// For two units A, B of that pixel (adjacent octets) one v_permlane32_swap per dword (lanes 32-63 of its first operand swap
+// with lanes 0-31 of the second) leaves lanes 0-31 with the whole unit A and lanes 32-63 with the whole unit B: ONE 16-byte
+// store per lane instead of two 8-byte ones (an epilogue of 8-byte stores is store-issue-bound, not byte-bound).
+__device__ __forceinline__ uint4 pair_units(uint2 a, uint2 b) {
+    const auto s0 = __builtin_amdgcn_permlane32_swap(a.x, b.x, false, false);
+    const auto s1 = __builtin_amdgcn_permlane32_swap(a.y, b.y, false, false);
+    const unsigned a0 = s0[0], b0 = s0[1], a1 = s1[0], b1 = s1[1];  // (named: hipcc's bit_cast / use of a vector ELEMENT is fragile)
+    return uint4{a0, a1, b0, b1};
+}
+
 // Transposed-conv scatter: n = co_real*(uh*2) + a*2 + bb; registers (r, r+1), r even, are bb = 0/1 of one (co_real, a),
 // so each lane writes 8 contiguous bytes and a half-wave a contiguous 256-B run of the up-sampled row.
 template <int NCO, int NPX, int PW>
@@ -160,27 +171,40 @@ __device__ __forceinline__ void store_tile(const ConvArgs& p, f32x16 (&acc)[NCO]
                 if (khalf == 0 && y < p.mask_T) mask_pixel(p, b, y, x, l[0], l[1], l[2]);
             } else if ((FLAGS & F_OUTBF16) != 0) {
                 // blocked bf16 layout: unit (octet, y, x) = 16 B = 8 channels; this lane holds channels 4*khalf..+3 of the
-                // four octets g of its 32-cout tile -> one 8-byte store per octet (the khalf pair completes the unit)
-                if (y < p.H) {
+                // four octets g of its 32-cout tile (8 bytes each; the khalf partner holds the other 8): per octet PAIR the
+                // halves are exchanged (pair_units) and lane khalf stores the whole unit of octet g + khalf
+                {
                     const int noct = p.out_noct ? p.out_noct : p.N / 8;
                     const size_t clip = (size_t)b * noct * HW;
                     typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const size_t unit = clip + (size_t)(p.out_oct0 + (n0 + co * 32) / 8 + g) * HW + (size_t)y * p.W + x;
-                        bf16x4 hi, lo, ac;
+                    for (int g = 0; g < 4; g += 2) {
+                        uint2 hi2[2], lo2[2], ac2[2];
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const float v = val[px][4 * g + i];
-                            hi[i] = (__bf16)v;
-                            lo[i] = (__bf16)(v - (float)hi[i]);
-                            if (p.out_bf16_act) ac[i] = (__bf16)leaky(v * as4[g][i] + ah4[g][i]);
+                        for (int h = 0; h < 2; ++h) {
+                            bf16x4 hi, lo, ac;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const float v = val[px][4 * (g + h) + i];
+                                hi[i] = (__bf16)v;
+                                lo[i] = (__bf16)(v - (float)hi[i]);
+                                ac[i] = p.out_bf16_act ? (__bf16)leaky(v * as4[g + h][i] + ah4[g + h][i]) : (__bf16)0.f;
+                            }
+                            hi2[h] = __builtin_bit_cast(uint2, hi);
+                            lo2[h] = __builtin_bit_cast(uint2, lo);
+                            ac2[h] = __builtin_bit_cast(uint2, ac);
                         }
-                        *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(p.out_bf16) + unit * 16 + khalf * 8) = hi;
-                        if (p.out_bf16_lo)
-                            *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(p.out_bf16_lo) + unit * 16 + khalf * 8) = lo;
-                        if (p.out_bf16_act)
-                            *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(p.out_bf16_act) + unit * 16 + khalf * 8) = ac;
+                        const size_t unit = clip + (size_t)(p.out_oct0 + (n0 + co * 32) / 8 + g + khalf) * HW + (size_t)min(y, p.H - 1) * p.W + x;
+                        const uint4 uh = pair_units(hi2[0], hi2[1]);
+                        if (y < p.H) *reinterpret_cast<uint4*>(reinterpret_cast<char*>(p.out_bf16) + unit * 16) = uh;
+                        if (p.out_bf16_lo) {
+                            const uint4 ul = pair_units(lo2[0], lo2[1]);
+                            if (y < p.H) *reinterpret_cast<uint4*>(reinterpret_cast<char*>(p.out_bf16_lo) + unit * 16) = ul;
+                        }
+                        if (p.out_bf16_act) {
+                            const uint4 ua = pair_units(ac2[0], ac2[1]);
+                            if (y < p.H) *reinterpret_cast<uint4*>(reinterpret_cast<char*>(p.out_bf16_act) + unit * 16) = ua;
+                        }
                     }
                 }
             } else if (y < p.H) {
@@ -212,17 +236,24 @@ __device__ __forceinline__ void store_tile(const ConvArgs& p, f32x16 (&acc)[NCO]
                         typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
                         const size_t clipo = (size_t)b * (p.N / 8) * Ho * Wo;
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const size_t unit = clipo + (size_t)((n0 + co * 32) / 8 + g) * Ho * Wo + (size_t)(y >> 1) * Wo + (x >> 1);
-                            bf16x4 raw, act;
+                        for (int g = 0; g < 4; g += 2) {  // octet pairs: whole 16-byte units per lane (pair_units)
+                            uint2 raw2[2], act2[2];
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                raw[i] = (__bf16)pooled[4 * g + i];
-                                act[i] = (__bf16)leaky(pooled[4 * g + i] * ps4[g][i] + ph4[g][i]);
+                            for (int h = 0; h < 2; ++h) {
+                                bf16x4 raw, act;
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) {
+                                    raw[i] = (__bf16)pooled[4 * (g + h) + i];
+                                    act[i] = (__bf16)leaky(pooled[4 * (g + h) + i] * ps4[g + h][i] + ph4[g + h][i]);
+                                }
+                                raw2[h] = __builtin_bit_cast(uint2, raw);
+                                act2[h] = __builtin_bit_cast(uint2, act);
                             }
+                            const size_t unit = clipo + (size_t)((n0 + co * 32) / 8 + g + khalf) * Ho * Wo + (size_t)(y >> 1) * Wo + (x >> 1);
+                            const uint4 ur = pair_units(raw2[0], raw2[1]), ua = pair_units(act2[0], act2[1]);
                             if (!(lane & 1) && y + 1 < p.H) {
-                                *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(p.pool_bf16) + unit * 16 + khalf * 8) = raw;
-                                *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(p.pool_bf16_act) + unit * 16 + khalf * 8) = act;
+                                *reinterpret_cast<uint4*>(reinterpret_cast<char*>(p.pool_bf16) + unit * 16) = ur;
+                                *reinterpret_cast<uint4*>(reinterpret_cast<char*>(p.pool_bf16_act) + unit * 16) = ua;
                             }
                         }
                     } else {

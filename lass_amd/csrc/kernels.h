@@ -122,6 +122,16 @@ hipError_t lass_launch_enc1_fused_bf16(const ConvArgs& p, const ConvArgs& q, hip
 bool lass_dec6_fused_bf16_supported(const ConvArgs& p, const ConvArgs& q);
 hipError_t lass_launch_dec6_fused_bf16(const ConvArgs& p, const ConvArgs& q, hipStream_t stream);
 
+// ... and the same block with decoder_block6's transposed conv computed inside (the up-sampled half of the concat never goes
+// to HBM).  u: in_bf16 = the previous decoder's activated blocked-bf16 output (B, 64/8, H/2, W/2, 8), w_bf16 = the transposed
+// conv's bf16 weights, w2_bf16 = the composed shortcut weights (lass_launch_compose_up_shortcut -> lass_launch_weights_bf16),
+// H, W = the low resolution, Cin = 64
+bool lass_dec6u_fused_bf16_supported(const ConvArgs& p, const ConvArgs& q, const ConvArgs& u);
+hipError_t lass_launch_dec6u_fused_bf16(const ConvArgs& p, const ConvArgs& q, const ConvArgs& u, hipStream_t stream);
+// out[((a*2+bb) * Nsc + n) * Cin + ci] = sum_co wsc[n][co] * wt[ci][co][a][bb]   (f32; wsc (Nsc, Ccat, 1, 1), wt (Cin, Cup, 2, 2))
+hipError_t lass_launch_compose_up_shortcut(const float* wsc, const float* wt, int Cin, int Cup, int Ccat, int Nsc, float* out,
+                                           hipStream_t stream);
+
 // ---- stft.hip -----------------------------------------------------------------------------------------------------
 // Multi-resolution analysis (scripts/precompute_stfts.py:19-58,573-590): nwin centred STFTs (n_fft = win in {256, 512,
 // 1024, 2048}, periodic Hann, reflect pad, common hop) of the same waveforms in one launch, torchlibrosa-magphase

@@ -496,6 +496,17 @@ def test_bf16_mode_convblock_and_waveform(synthetic_sd, oracle_sd, monkeypatch):
     rel = _relerr(out, ref)
     print("bf16 waveform relative RMS error", rel)
     assert rel < 5e-2, rel
+    # decoder_block6's transposed conv inside its fused kernel (default) composes the shortcut with it - weights rounded once,
+    # bf16 noise apart from the three-launch form (test_bf16_fused_upconv_vs_separate_launch); the exact A/B pairs below are
+    # taken against the three-launch form
+    monkeypatch.setenv("LASS_FUSE_UP", "0")
+    m1 = ResUNet30(1, 1, 512)
+    m1.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synthetic_sd.items()})
+    out_fu = out
+    out = m1.to(DEV).eval().set_compute_dtype("bf16")(
+        {"mixture": torch.from_numpy(mix)[:, None, :].to(DEV), "condition": torch.from_numpy(c2).to(DEV)})["waveform"]
+    monkeypatch.delenv("LASS_FUSE_UP")
+    assert _relerr(out, ref) < 5e-2 and _relerr(out_fu, out) < 1.5e-2
     # the blocked bf16 concat copies (default) round exactly what the f32-concat path rounds while staging: same waveform
     monkeypatch.setenv("LASS_FUSE_CATB", "0")
     m2 = ResUNet30(1, 1, 512)
@@ -514,6 +525,46 @@ def test_bf16_mode_convblock_and_waveform(synthetic_sd, oracle_sd, monkeypatch):
     monkeypatch.delenv("LASS_FUSE_BLOCK")
     print("fused vs two-launch encoder_block1 / decoder_block6 (bf16): relative RMS difference", _relerr(out3, out))
     assert _relerr(out3, out) < 1e-5
+
+
+def test_bf16_fused_upconv_vs_separate_launch(synthetic_sd, oracle_sd, monkeypatch):
+    """decoder_block6's transposed conv inside the fused decoder kernel (default; the up-sampled half of the concat is never
+    written) against the three-launch form (LASS_FUSE_UP=0: transposed conv -> blocked copies -> fused block).  The fused
+    form composes the 1x1 shortcut with the transposed conv (weights rounded once), so the two agree to bf16 rounding
+    noise, not bit for bit: compared on the separated spectrum (workspace tap, every bin - tile borders and image edges
+    included) and on the waveform; both forms against the f32 oracle as in test_bf16_mode_convblock_and_waveform.
+    L = 25 600 -> 161 frames -> 192 padded rows: 24 row tiles, masked rows beyond the last frame."""
+    from lass_amd.resunet import ResUNet30
+    from oracle import resunet as orr
+    B, L = 2, 25600
+    _, mix = synthetic.make_mixtures(B, L)
+    cond = synthetic.make_condition(B)
+    inp = {"mixture": torch.from_numpy(mix)[:, None, :].to(DEV), "condition": torch.from_numpy(cond).to(DEV)}
+    res = {}
+    for tag, env in (("fused", None), ("separate", "0")):
+        if env is not None:
+            monkeypatch.setenv("LASS_FUSE_UP", env)
+        m = ResUNet30(1, 1, 512)
+        m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synthetic_sd.items()})
+        m = m.to(DEV).eval().set_compute_dtype("bf16")
+        out = m(inp)["waveform"].cpu()
+        T = 1 + L // 160
+        spec = [m.engine.workspace_tensor(n, B, L)[:, :, :T].clone().cpu() for n in ("out_real", "out_imag")]
+        res[tag] = (out, spec)
+        if env is not None:
+            monkeypatch.delenv("LASS_FUSE_UP")
+    ref = orr.forward(oracle_sd, {"mixture": torch.from_numpy(mix)[:, None, :], "condition": torch.from_numpy(cond)})["waveform"]
+    for tag in res:
+        assert _relerr(res[tag][0], ref) < 5e-2, tag
+    d = _relerr(res["fused"][0], res["separate"][0])
+    print("bf16: transposed conv inside decoder_block6's kernel vs its own launch, waveform relative RMS difference", d)
+    assert 1e-7 < d < 1.5e-2, d   # not identical (composed shortcut weights), bf16 noise
+    for a, bq in zip(res["fused"][1], res["separate"][1]):
+        scale = float(bq.abs().max())
+        err = (a - bq).abs()
+        # a wrong pixel mapping / border rule shows as an isolated large error: bound the maximum over all bins
+        assert float(err.max()) < 0.08 * scale, float(err.max()) / scale
+        assert float(err.pow(2).mean().sqrt()) < 1e-2 * float(bq.pow(2).mean().sqrt())
 
 
 @pytest.mark.parametrize("mode", ["bf16", "bf16x3"])
