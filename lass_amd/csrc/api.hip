@@ -52,6 +52,7 @@ struct ResBlock {  // one ConvBlockRes
     float *w1 = nullptr, *w2 = nullptr, *wsc = nullptr;  // re-laid-out
     float *u1 = nullptr, *u2 = nullptr, *usc = nullptr;  // Winograd-domain copies (when enabled)
     float *u1r = nullptr, *u2r = nullptr, *uscr = nullptr;  // 32-cout blocks: resident LDS images of wino32.hip
+    float *u1f = nullptr, *u2f = nullptr;                   // conv1 / conv2 in the F(4x4,3x3) domain (wino4.hip), deep-K blocks
     void *b1 = nullptr, *b2 = nullptr, *bsc16 = nullptr;  // bf16 copies (LASS_COMPUTE_BF16 / _BF16X3)
     void *b1l = nullptr, *b2l = nullptr, *bscl = nullptr;  // lo halves of the hi+lo split (LASS_COMPUTE_BF16X3)
     const float* bsc = nullptr;                         // raw shortcut bias
@@ -104,6 +105,8 @@ struct lass_ctx {
     // profiling
     int compute_mode = LASS_COMPUTE_F32;
     bool wino = true;          // Winograd F(2x2,3x3) kernels for the 3x3 convs at W >= 32 (LASS_WINO=0: direct only)
+    int wino4_mincin = 64;     // 3x3 convs with at least that many input channels (and >= 32-wide images) run as Winograd
+                               // F(4x4,3x3) (wino4.hip); LASS_WINO4=<min Cin>, 0 = off (F(2x2,3x3) everywhere)
     bool wino32 = true;        // weights-resident persistent kernel for the 32-cout layers (LASS_WINO32=0: wino.hip everywhere)
     bool fuse_preconv = true;  // LASS_FUSE_PRECONV=0 materialises pre_conv's output with its own kernel
     bool fuse_pool = true;  // LASS_FUSE_POOL=0 selects the stand-alone pool kernel (A/B + parity of both paths)
@@ -425,7 +428,7 @@ int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int
         p.in = x0; p.in_bs = HW;
         p.pre_w = pre->w; p.pre_b = pre->b;
     }
-    p.w_wino = rb.u1; p.w_wino32 = rb.u1r;
+    p.w_wino = rb.u1; p.w_wino32 = rb.u1r; p.w_wino4 = rb.u1f;
     p.w_bf16 = rb.b1; p.w_bf16_lo = rb.b1l;
     const bool bf1 = c->compute_mode != LASS_COMPUTE_F32 && rb.b1 && rb.b2 && lass_bf16_supported(p) &&
                      (!x0 || W % 32 == 0) && rb.cout % 16 == 0 && (rb.cin == rb.cout || (rb.bsc16 && rb.cin % 16 == 0));
@@ -441,6 +444,8 @@ int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int
         ProfScope ps(c, st, P_CONV3X3);
         if (bf1)
             HIP_TRY(c, lass_launch_conv_bf16(x0 ? CONV1_ACT_PRE : CONV1_ACT, p, st));
+        else if (wino1 && !x0 && rb.u1f && lass_wino4_supported(CONV1_ACT, p))
+            HIP_TRY(c, lass_launch_wino4(CONV1_ACT, p, st));
         else if (wino1 && c->wino32 && lass_wino32_supported(x0 ? CONV1_ACT_PRE : CONV1_ACT, p))
             HIP_TRY(c, lass_launch_wino32(x0 ? CONV1_ACT_PRE : CONV1_ACT, p, st));
         else if (wino1)
@@ -453,7 +458,7 @@ int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int
     q.in = a2; q.in_bs = rb.cout * HW; q.Cin = rb.cout; q.w = rb.w2; q.Nw = rb.cout; q.N = rb.cout;
     q.out = out; q.out_bs = out_bs; q.B = B; q.H = H; q.W = W;
     q.pool_out = pool_out; q.pool_h = pool_h; q.pool_bs = pool_bs;
-    q.w_wino = rb.u2; q.w2_wino = rb.usc; q.w_wino32 = rb.u2r; q.w2_wino32 = rb.uscr;
+    q.w_wino = rb.u2; q.w2_wino = rb.usc; q.w_wino32 = rb.u2r; q.w2_wino32 = rb.uscr; q.w_wino4 = rb.u2f;
     if (mh) {  // the block output is consumed by the fused head and never written
         q.out = nullptr;
         q.mask_w = rawp(c, "base.after_conv.weight"); q.mask_b = rawp(c, "base.after_conv.bias");
@@ -533,6 +538,8 @@ int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int
     } else {
         if (bf2)
             HIP_TRY(c, lass_launch_conv_bf16(CONV2_SHORTCUT, q, st));
+        else if (wino2 && rb.u2f && lass_wino4_supported(CONV2_SHORTCUT, q))
+            HIP_TRY(c, lass_launch_wino4(CONV2_SHORTCUT, q, st));
         else if (wino2 && c->wino32 && lass_wino32_supported(CONV2_SHORTCUT, q))
             HIP_TRY(c, lass_launch_wino32(CONV2_SHORTCUT, q, st));
         else if (wino2)
@@ -702,6 +709,7 @@ static int create_impl(lass_ctx** out, int device_id, const Geometry& geom) {
     if (const char* e = getenv("LASS_FUSE_CATB")) c->fuse_catb = atoi(e) != 0;
     if (const char* e = getenv("LASS_FUSE_BLOCK")) c->fuse_block = atoi(e) != 0;
     if (const char* e = getenv("LASS_FUSE_UP")) c->fuse_up = atoi(e) != 0;
+    if (const char* e = getenv("LASS_WINO4")) c->wino4_mincin = atoi(e);
     if (const char* e = getenv("LASS_FUSE_PRECONV")) c->fuse_preconv = atoi(e) != 0;
     if (const char* e = getenv("LASS_GRAPH")) c->use_graph = atoi(e) != 0;
     c->prof.resize(P_COUNT);
@@ -857,6 +865,7 @@ int lass_finalize(lass_ctx* c, int compute_mode) {
         HIP_TRY(c, lass_launch_relayout_conv(w2, rb.cout, rb.cout, 9, rb.w2, st));
         rb.u1 = rb.u2 = rb.usc = nullptr;
         rb.u1r = rb.u2r = rb.uscr = nullptr;
+        rb.u1f = rb.u2f = nullptr;
         rb.b1 = rb.b2 = rb.bsc16 = rb.b1l = rb.b2l = rb.bscl = nullptr;
         const bool bfm = c->compute_mode == LASS_COMPUTE_BF16 || c->compute_mode == LASS_COMPUTE_BF16X3;
         const bool split = c->compute_mode == LASS_COMPUTE_BF16X3;
@@ -881,6 +890,14 @@ int lass_finalize(lass_ctx* c, int compute_mode) {
                 return LASS_ERR_HIP;
             HIP_TRY(c, lass_launch_wino_weights(w1, rb.cout, rb.cin, rb.u1, st));
             HIP_TRY(c, lass_launch_wino_weights(w2, rb.cout, rb.cout, rb.u2, st));
+            if (c->wino4_mincin > 0 && rb.cin >= c->wino4_mincin && rb.cin % 8 == 0 && rb.cout % 32 == 0) {
+                if (dev_alloc(c, &rb.u1f, (size_t)36 * rb.cout * rb.cin)) return LASS_ERR_HIP;
+                HIP_TRY(c, lass_launch_wino4_weights(w1, rb.cout, rb.cin, rb.u1f, st));
+            }
+            if (c->wino4_mincin > 0 && rb.cout >= c->wino4_mincin && rb.cin != rb.cout && rb.cout % 32 == 0 && rb.cin % 8 == 0) {
+                if (dev_alloc(c, &rb.u2f, (size_t)36 * rb.cout * rb.cout)) return LASS_ERR_HIP;
+                HIP_TRY(c, lass_launch_wino4_weights(w2, rb.cout, rb.cout, rb.u2f, st));
+            }
             // full-resolution 32-channel blocks, and encoder_block2 (32 -> 64) as two 32-cout slices: wino32.hip
             if ((rb.cout == 32 && rb.cin % 8 == 0) || (rb.cout == 64 && rb.cin == 32)) {
                 const size_t ns = rb.cout / 32;

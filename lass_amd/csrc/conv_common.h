@@ -65,11 +65,13 @@ __device__ __forceinline__ void tconv_store(const ConvArgs& p, f32x16 (&acc)[NCO
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
                     for (int bb = 0; bb < 2; ++bb) {
+                        // one v_permlane32_swap: lanes 32-63 of the a = 0 register (odd channel) swap with lanes 0-31 of the
+                        // a = 1 register (even channel): first result = even channel, second = odd channel, row a = khalf
                         const float lo_a = acc[co][px][4 * g + bb], hi_a = acc[co][px][4 * g + 2 + bb];  // a = 0 / 1
-                        const float keep = khalf ? hi_a : lo_a, send = khalf ? lo_a : hi_a;
-                        const float other = __shfl_xor(send, 32, 64);
-                        ch[bb][2 * g] = khalf ? other : keep;      // even channel: from the khalf = 0 lane
-                        ch[bb][2 * g + 1] = khalf ? keep : other;  // odd channel: from the khalf = 1 lane
+                        const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, lo_a), __builtin_bit_cast(unsigned, hi_a), false, false);
+                        const unsigned r0 = sw[0], r1 = sw[1];
+                        ch[bb][2 * g] = __builtin_bit_cast(float, r0);
+                        ch[bb][2 * g + 1] = __builtin_bit_cast(float, r1);
                     }
                 if (y >= p.H) continue;
                 const int oct = (n0 + co * 32) / 32;  // octet of this co-tile among the launch's output channels

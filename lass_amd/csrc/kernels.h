@@ -40,6 +40,7 @@ struct ConvArgs {
     int up_h = 1;  // TCONV: vertical stride (1 or 2); horizontal stride is always 2
     const float* w_wino = nullptr;   // Winograd-domain weights U[16][Cin][Nw] (wino.hip)
     const float* w2_wino = nullptr;  // Winograd-domain shortcut weights [4][Cin2][Nw]
+    const float* w_wino4 = nullptr;    // Winograd F(4x4,3x3)-domain weights: LDS images of wino4.hip (36 * Cin * Nw floats)
     const float* w_wino32 = nullptr;   // 32-cout layers: the resident LDS image of wino32.hip (Cin * 512 floats)
     const float* w2_wino32 = nullptr;  // ... of the shortcut weights (Cin2 * 128 floats)
     const void* w_bf16 = nullptr;    // bf16 weights [Cin/16][tap][2][Nw][8] (conv_bf16.hip)
@@ -107,6 +108,11 @@ bool lass_wino32_supported(ConvKind kind, const ConvArgs& p);
 hipError_t lass_launch_wino32(ConvKind kind, const ConvArgs& p, hipStream_t stream);
 hipError_t lass_launch_wino32_weights(const float* w, int Cout, int Cin, float* U, hipStream_t stream);            // w (Cout, Cin, 3, 3), Cout % 32 == 0: one image per 32-cout slice
 hipError_t lass_launch_wino32_shortcut_weights(const float* w, int Cout, int Cin, float* U, hipStream_t stream);   // w (Cout, Cin, 1, 1)
+
+// ---- wino4.hip (Winograd F(4x4,3x3): 36 instead of 64 MFMA multiplies per 16 outputs; the conv1 kind, W % 32 == 0) ----------
+bool lass_wino4_supported(ConvKind kind, const ConvArgs& p);
+hipError_t lass_launch_wino4(ConvKind kind, const ConvArgs& p, hipStream_t stream);
+hipError_t lass_launch_wino4_weights(const float* w, int Cout, int Cin, float* U, hipStream_t stream);  // w (Cout, Cin, 3, 3)
 
 // ---- conv_bf16.hip (bf16-MFMA variant of the 3x3 kinds; W multiple of 32, Cin multiple of 16) ----------------------
 bool lass_bf16_supported(const ConvArgs& p);

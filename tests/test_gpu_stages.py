@@ -297,3 +297,62 @@ def test_wino32_resident_kernel_vs_oracle_and_wino(synthetic_sd, oracle_sd, monk
         assert got.shape == ref.shape
         assert _relerr(got, ref) < 5e-6, _relerr(got, ref)     # the bar of test_convblock_vs_oracle
         assert _relerr(got, old) < 2e-6, _relerr(got, old)     # same products, another summation order in B^T d B
+
+
+W4_BLOCKS = [  # (module prefix, film site stem, cin, cout, H, W): shapes with one block column / row, image edges on every side
+    ("base.decoder_block5.conv_block2", "decoder_block5->conv_block2", 128, 64, 16, 64),    # 8 x 64 blocks, two block rows
+    ("base.decoder_block4.conv_block2", "decoder_block4->conv_block2", 256, 128, 32, 32),   # 16 x 32 blocks (W % 64 != 0)
+    ("base.decoder_block3.conv_block2", "decoder_block3->conv_block2", 512, 256, 8, 128),   # one block row, two block columns
+    ("base.decoder_block2.conv_block2", "decoder_block2->conv_block2", 768, 384, 16, 32),
+    ("base.encoder_block4.conv_block1", "encoder_block4->conv_block1", 128, 256, 24, 64),
+]
+
+
+@pytest.mark.parametrize("prefix,stem,cin,cout,H,W", W4_BLOCKS)
+def test_wino4_convblock_vs_oracle_and_wino(synthetic_sd, oracle_sd, monkeypatch, prefix, stem, cin, cout, H, W):
+    """wino4.hip - conv1 of a ConvBlockRes (resunet.py:101-119,147-165) as Winograd F(4x4,3x3): 36 instead of 64 MFMA multiplies
+    per 16 outputs, 6x6 transforms (constants up to 8 and down to 1/24) - against the oracle and against the F(2x2,3x3) kernels
+    (LASS_WINO4=0) on the same block.  Rounding error per layer is ~6x that of F(2x2,3x3): the block bar is 2e-5 relative here
+    (5e-6 for the F(2x2,3x3) path, test_convblock_vs_oracle); the end-to-end bar stays north_star's 1e-4 RMS."""
+    from lass_amd.engine import Engine
+    from oracle import resunet as orr
+    B = 2
+    g = torch.Generator().manual_seed(H * 1000 + W + cin)
+    x = torch.randn(B, cin, H, W, generator=g)
+    cond = torch.from_numpy(synthetic.make_condition(B))
+    ys = {}
+    for sw in ("64", "0"):
+        monkeypatch.setenv("LASS_WINO4", sw)
+        e = Engine(DEV)
+        e.load_state_dict(synthetic_sd)
+        monkeypatch.delenv("LASS_WINO4")
+        ys[sw] = e.convblock(prefix, x.to(DEV), e.film(cond.to(DEV)), cout).cpu()
+    ref = orr.conv_block_res(oracle_sd, prefix, x, orr.film(oracle_sd, cond, stem + "->beta1"),
+                             orr.film(oracle_sd, cond, stem + "->beta2"))
+    e4, e2 = _relerr(ys["64"], ref), _relerr(ys["0"], ref)
+    print(prefix, "relative RMS error vs oracle: F(4x4,3x3)", e4, " F(2x2,3x3)", e2, " max abs", float((ys["64"] - ref).abs().max()))
+    assert e2 < 5e-6 and e4 < 2e-5, (e4, e2)
+    assert float((ys["64"] - ref).abs().max()) < 3e-4 * max(1.0, float(ref.abs().max()))
+    assert not torch.equal(ys["64"], ys["0"])   # really another kernel
+
+
+def test_wino4_encoder_block_with_fused_pool(synthetic_sd, oracle_sd, monkeypatch):
+    """conv2 + direct 1x1 shortcut + bias + the block's fused 2x2 avg-pool in wino4.hip (resunet.py:147-165,186-198):
+    encoder_block4 (128 -> 256) and encoder_block3 (64 -> 128) as whole blocks against the oracle."""
+    from lass_amd.engine import Engine
+    from oracle import resunet as orr
+    monkeypatch.setenv("LASS_WINO4", "64")
+    e = Engine(DEV)
+    e.load_state_dict(synthetic_sd)
+    monkeypatch.delenv("LASS_WINO4")
+    B = 2
+    cond = torch.from_numpy(synthetic.make_condition(B))
+    shift = e.film(cond.to(DEV))
+    g = torch.Generator().manual_seed(77)
+    for name, cin, cout, H, W in (("encoder_block4", 128, 256, 16, 64), ("encoder_block3", 64, 128, 32, 32)):
+        x = torch.randn(B, cin, H, W, generator=g)
+        y, pool = e.encoder_block("base." + name, x.to(DEV), shift, cout, (2, 2))
+        ref = orr.conv_block_res(oracle_sd, f"base.{name}.conv_block1", x, orr.film(oracle_sd, cond, f"{name}->conv_block1->beta1"),
+                                 orr.film(oracle_sd, cond, f"{name}->conv_block1->beta2"))
+        assert _relerr(y.cpu(), ref) < 2e-5, (name, _relerr(y.cpu(), ref))
+        assert _relerr(pool.cpu(), F.avg_pool2d(ref, (2, 2))) < 2e-5, name

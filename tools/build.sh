@@ -2,7 +2,7 @@
 # Build liblass_hip.so (and optionally the diagnostic variant / ISA) from anywhere.  Usage: tools/build.sh [diag] [asm FILE]
 set -e
 cd "$(dirname "$0")/../lass_amd/csrc"
-SRC="api.hip conv.hip wino.hip wino32.hip conv_bf16.hip conv_bf16_fused.hip stft.hip misc.hip"
+SRC="api.hip conv.hip wino.hip wino32.hip wino4.hip conv_bf16.hip conv_bf16_fused.hip stft.hip misc.hip"
 hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared -o liblass_hip.so $SRC -Rpass-analysis=kernel-resource-usage 2> build.log || { grep -E "error" build.log | head -20; exit 1; }
 python3 - <<'PY'
 import sys; sys.path.insert(0, "../..")

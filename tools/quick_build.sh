@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")/../lass_amd/csrc"
 mkdir -p .obj
-SRC="api.hip conv.hip wino.hip wino32.hip conv_bf16.hip conv_bf16_fused.hip stft.hip misc.hip"
+SRC="api.hip conv.hip wino.hip wino32.hip wino4.hip conv_bf16.hip conv_bf16_fused.hip stft.hip misc.hip"
 NEWEST_H=$(ls -t *.h ../../include/lass_hip.h | head -1)
 pids=()
 for s in $SRC; do
