@@ -32,7 +32,8 @@ sys.path.insert(0, ROOT)
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2, 64 FLOP/clk/SIMD @ 2.4 GHz
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
-WINO_MULT_REDUCTION = 9.0 / 4.0  # F(2x2,3x3): 16 multiplies per 2x2 output tile and (cin,cout) instead of 36
+# Winograd multiply counts per output pixel and (cin, cout) pair: F(2x2,3x3) 4 (16 per 2x2 tile), F(4x4,3x3) 2.25 (36 per 4x4
+# tile), direct 9.  Which 3x3 layers run as F(4x4,3x3) is lass_amd.arch.wino4_routed (mirror of the C dispatch).
 
 
 def parse_args(argv=None):
@@ -52,8 +53,9 @@ def parse_args(argv=None):
                     help="torch.distributed backend of the one exchange step; gloo also lets ranks share a GPU "
                          "(rehearsal on a 1-GPU box)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-full", action="store_true",
-                    help="SURVEY 8(d) protocol in full at B=16 as well (3 warm-up + 10 timed; minutes of CPU time)")
+    ap.add_argument("--cpu-short", action="store_true",
+                    help="cpu_baseline at B=16 with 1 warm-up + 3 timed forwards instead of SURVEY 8(d)'s 3 + 10 (~3 min of CPU time)")
+    ap.add_argument("--cpu-full", action="store_true", help="(default since round 4; kept for old command lines)")
     ap.add_argument("--print-launch", action="store_true", help="N>1 parent: print the launch command and exit")
     return ap.parse_args(argv)
 
@@ -82,18 +84,25 @@ def parent_launch(args, argv) -> int:
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "4")
-    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, text=True)
-    line = None
+    # stdout and stderr of the ranks in one stream: rank 0's JSON line is picked out, everything else goes to our stderr (on a
+    # failure only its tail, marked, so that the failing rank's traceback is the last thing in the log)
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    line, rest = None, []
     for ln in p.stdout.splitlines():
         if ln.startswith("{") and '"metric"' in ln:
             line = ln
         else:
-            print(ln, file=sys.stderr)
-    if line is not None:
-        print(line, flush=True)
+            rest.append(ln)
+    if p.returncode != 0:
+        print(f"bench.py: the launcher exited with code {p.returncode}; last output of the ranks:", file=sys.stderr)
+        rest = rest[-60:]
+    for ln in rest:
+        print(ln, file=sys.stderr)
     if p.returncode == 0 and line is None:
         print("bench.py: the ranks printed no result line", file=sys.stderr)
         return 1
+    if line is not None and p.returncode == 0:
+        print(line, flush=True)
     return p.returncode
 
 
@@ -158,11 +167,10 @@ def traffic_fields(dtype, alg_bytes_launch, enabled=True):
             "traffic_fetch_calibration": t.get("fetch_calibration")}
 
 
-def cpu_baseline(sd, length, full=False):
+def cpu_baseline(sd, length, full=True):
     """The oracle (CPU restatement of the reference path, kind "port") timed on this box's host cores, SURVEY 8(d)
-    protocol: B=1 with 3 warm-up + 10 timed forwards, median; B=16 the same when --cpu-full, else 1 warm-up + 3 timed,
-    median (a B=16 forward takes ~15 s of CPU time and the default bench must finish within minutes: the deviation from
-    the 3 + 10 protocol is stated in `sample`)."""
+    protocol: B=1 and B=16, each with 3 warm-up + 10 timed forwards, median (a B=16 forward takes ~14 s of CPU time: ~3 min
+    in all; --cpu-short = 1 warm-up + 3 timed at B=16, stated in `sample`)."""
     import numpy as np
     import torch
     from lass_amd import synthetic
@@ -194,19 +202,20 @@ def cpu_baseline(sd, length, full=False):
                       f"{torch.get_num_threads()} threads: B=1 3 warm-up + 10 timed forwards, median {t1:.3f} s "
                       f"(min {min(ts1):.3f}, max {max(ts1):.3f}); B=16 {w16} warm-up + {n16} timed, median {t16:.2f} s "
                       f"(min {min(ts16):.2f}, max {max(ts16):.2f})"
-                      + ("" if full else "; SURVEY 8(d) asks 3 + 10 at B=16 too (--cpu-full), shortened to keep the "
-                                         "default run within minutes")}
+                      + ("" if full else "; SURVEY 8(d) asks 3 + 10 at B=16 too: shortened by --cpu-short")}
 
 
-def conv_flops(rows, B, wino):
+def conv_flops(rows, B, wino, wino4=frozenset()):
     """(algorithmic, executed) FLOPs per step of the conv3x3_mfma class (3x3 convs + the 1x1 shortcuts fused into them).
     Executed: a Winograd F(2x2,3x3) launch performs 16 instead of 36 multiplies per 2x2 tile and (cin, cout) - 4/9 of
-    the direct count; the transform-domain shortcut performs 4 per tile = the direct 1x1 count."""
+    the direct count; an F(4x4,3x3) launch (row names in `wino4`) 36 instead of 144 per 4x4 tile - 1/4; the shortcut
+    (transform domain or direct) performs the direct 1x1 count."""
     alg = exe = 0.0
     for r in rows:
         if r["kind"] == "3x3":
             alg += 2.0 * B * r["macs"]
-            exe += 2.0 * B * r["macs"] * ((4.0 / 9.0) if (wino and r["h"] % 2 == 0) else 1.0)
+            f = 0.25 if (wino and r["name"] in wino4) else ((4.0 / 9.0) if (wino and r["h"] % 2 == 0) else 1.0)
+            exe += 2.0 * B * r["macs"] * f
         elif r["name"].endswith(".shortcut"):
             alg += 2.0 * B * r["macs"]
             exe += 2.0 * B * r["macs"]
@@ -316,6 +325,10 @@ def main():
     extra_warm = max(0, 3 - args.warmup) if eng.graph_stats()[0] else 0
     dt = timed(eng, args.steps, args.warmup + extra_warm)
     assert not check or torch.isfinite(out).all()
+    # the same step launched eagerly (no hipGraph replay): what the HIP-event-instrumented loop below runs on
+    eng.set_graph_replay(False)
+    dt_eager = timed(eng, args.steps, 1)
+    eng.set_graph_replay(True)
 
     # ---- the one exchange step: per-clip metric rows, all-gathered over the process group ---------------
     exch = {"rccl_ranks": 0, "allgather_ms": None, "backend": args.backend}
@@ -346,10 +359,12 @@ def main():
 
     rows = arch.conv_layer_table(arch.padded_frames(arch.frames_for(L)))
     wino = os.environ.get("LASS_WINO", "1") != "0"
+    w4thr = int(os.environ.get("LASS_WINO4", "64"))
+    w4rows = arch.wino4_routed(rows, w4thr) if wino else set()
 
     def mode_record(dtype, dt_mode, steps, prof_mode):
         """Roofline numbers of one compute mode from its timed and profiled loops."""
-        alg, exe_f32 = conv_flops(rows, B, wino)
+        alg, exe_f32 = conv_flops(rows, B, wino, w4rows)
         ms, launches = prof_mode["conv3x3_mfma"]
         per_step = ms / psteps * 1e-3
         if dtype == "f32":
@@ -375,9 +390,9 @@ def main():
     modes = {}
     want = args.modes
     if want == "auto":
-        want = "bf16,bf16x3,multistft" if (world == 1 and args.dtype == "f32") else "none"
+        want = "bf16,bf16x3,multistft,evaluator" if (world == 1 and args.dtype == "f32") else "none"
     want = [x for x in want.split(",") if x and x != "none"]
-    for m in [x for x in want if x != "multistft"]:
+    for m in [x for x in want if x not in ("multistft", "evaluator")]:
         model.set_compute_dtype(m)
         e2 = model.engine
         # >= 3 untimed steps: lass_separate captures its hipGraph on the third identical call, which must not fall inside
@@ -411,7 +426,7 @@ def main():
         assert not check or torch.isfinite(io[2]).all()
         pm = profiled(em, 2, io)
         rows_m = arch.ms_conv_layer_table(arch.padded_frames(arch.frames_for(Lm)))
-        alg_m, exe_m = conv_flops(rows_m, Bm, wino)
+        alg_m, exe_m = conv_flops(rows_m, Bm, wino, arch.wino4_routed(rows_m, w4thr) if wino else set())
         cls_s = pm["conv3x3_mfma"][0] / 2 * 1e-3
         tot_m = 2.0 * Bm * sum(r["macs"] for r in rows_m)
         modes["multistft_30s_32k"] = {
@@ -437,15 +452,50 @@ def main():
         gc.collect()
         torch.cuda.empty_cache()
 
+    if "evaluator" in want:
+        # SURVEY 8(f1), driver-timed: DCASEEvaluator.__call__ (dcase_evaluator.py:49-122) end to end on a synthetic validation set
+        # of 260 clips (16 full batches + a ragged tail of 4): WAV decode on prefetch threads -> pinned staging -> H2D -> device-side
+        # mixing at SNR -> lass_separate -> device-side SDR / SI-SDR -> means; 1 warm-up call, median of 3 timed calls, against the
+        # headline separator rate of this same run
+        import shutil
+        import tempfile
+        from lass_amd.audiosep import AudioSep, PrecomputedQueryEncoder
+        from lass_amd.evaluator import DCASEEvaluator
+        n_ev = 260
+        tmp = tempfile.mkdtemp(prefix="lass_eval_")
+        try:
+            csv_path = synthetic.write_validation_set(tmp, n_clips=n_ev, length=L)
+            plm = AudioSep(ss_model=model, query_encoder=PrecomputedQueryEncoder())
+            ev = DCASEEvaluator(16000, csv_path, os.path.join(tmp, "lass_validation"), batch_size=B)
+            ev(plm)
+            dts, outv = [], None
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                outv = ev(plm)
+                torch.cuda.synchronize()
+                dts.append(time.perf_counter() - t0)
+            dt_ev = sorted(dts)[1]
+            sep_rate = world * B * args.steps / dt
+            modes["evaluator_e2e"] = {
+                "workload": f"DCASEEvaluator.__call__ on {n_ev} synthetic 10 s mixtures (WAV files -> decode -> mix at SNR -> separate "
+                            f"-> SDR/SDRi/SI-SDR means), batch {B}, ragged tail of {n_ev % B}; 1 warm-up call, median of 3",
+                "clips_s": n_ev / dt_ev, "calls_s": [n_ev / d for d in dts], "separator_clips_s": sep_rate,
+                "evaluator_over_separator": n_ev / dt_ev / sep_rate,
+                "mean_sisdr_sdri_sdr": [float(v) for v in outv]}
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+
     if rank == 0:
-        alg_step, _ = conv_flops(rows, B, wino)
+        alg_step, exe_step = conv_flops(rows, B, wino, w4rows)
         total_flops = 2.0 * B * sum(r["macs"] for r in rows)
         traffic = traffic_fields(args.dtype, alg_bytes_launch_of(head), (B, L) == (16, 160000))
         alg_bytes_launch = alg_bytes_launch_of(head)
-        kernel = {"f32": "wino_kernel<...> x19 + wino32_kernel<...> x7: 3x3 convs as Winograd F(2x2,3x3) on v_mfma_f32_16x16x4_f32 + fused 1x1 "
-                         "shortcuts (conv3x3_mfma class)" if wino else "conv_kernel (direct f32 MFMA)",
-                  "bf16": "conv_bf16_kernel x22 + enc1_fused / dec6_fused_bf16_kernel (a ConvBlockRes each): direct 3x3 + fused 1x1 "
-                          "shortcuts on v_mfma_f32_32x32x16_bf16",
+        kernel = {"f32": (f"wino4_kernel<...> x{len(w4rows)} (Winograd F(4x4,3x3): {', '.join(sorted(w4rows))}) + wino32_kernel / "
+                          f"wino_kernel x{26 - len(w4rows)} (F(2x2,3x3): the 32-cout full-resolution and the 16-/8-bin layers) on "
+                          "v_mfma_f32_16x16x4_f32, 1x1 shortcuts fused (conv3x3_mfma class)") if wino else "conv_kernel (direct f32 MFMA)",
+                  "bf16": "conv_bf16_kernel x22 + enc1_fused / dec6u_fused_bf16_kernel (a ConvBlockRes each, decoder_block6's with its "
+                          "transposed conv inside): direct 3x3 + fused 1x1 shortcuts on v_mfma_f32_32x32x16_bf16",
                   "bf16x3": "conv_bf16_kernel (split operands, 3 MFMAs per product) x26"}[args.dtype]
         res = {
             "metric": "clips/sec (10s@16kHz)", "value": world * B * args.steps / dt, "unit": "clips/s",
@@ -460,15 +510,20 @@ def main():
             "exchange": exch,
             "launch": {"hipgraph_replay": graph_on, "captures": graph_caps, "replays_in_headline_loops": graph_replays,
                        "extra_warmup_for_capture": extra_warm,
-                       "note": "the timed loop replays ONE captured hipGraph of the ~40 launches per step; the profiled "
-                               "loop (HIP events per kernel class) runs eagerly"},
+                       "eager_ms_per_step": dt_eager / args.steps * 1e3,
+                       "profiled_ms_per_step": sum(v for v in head["kernel_ms_per_step"].values()),
+                       "note": "ms_per_step / value: the timed loop replays ONE captured hipGraph of the ~40 launches per "
+                               "step; eager_ms_per_step: the same loop with replay switched off; kernel_ms_per_step / "
+                               "class_ms_per_step: a third, eager loop with HIP events around every kernel class (their sum = "
+                               "profiled_ms_per_step: events add the drain between classes)"},
             "roofline": {"bound": "mfma", "kernel": kernel,
                          "achieved": head["executed_tflops"], "peak": head["peak_tflops"], "unit": "TFLOP/s",
                          "frac": head["frac"],
                          "achieved_is": "EXECUTED MFMA FLOPs of the class per step / its HIP-event time per step "
                                         "(profiled loop); the algorithmic direct-conv rate is algorithmic_tflops",
                          "algorithmic_tflops": head["algorithmic_tflops"],
-                         "winograd_mult_reduction": WINO_MULT_REDUCTION if (args.dtype == "f32" and wino) else 1.0,
+                         "winograd_mult_reduction": (alg_step / exe_step) if (args.dtype == "f32" and wino) else 1.0,
+                         "winograd_f4x4_layers": sorted(w4rows) if args.dtype == "f32" else [],
                          "algorithmic_gflop_per_step": alg_step / 1e9,
                          **traffic,
                          "algorithmic_bytes_per_launch": alg_bytes_launch,
@@ -482,7 +537,7 @@ def main():
         if modes:
             res["modes"] = modes
         if world == 1 and not args.no_cpu_baseline and args.dtype == "f32":
-            res["cpu_baseline"] = cpu_baseline(sd, L, args.cpu_full)
+            res["cpu_baseline"] = cpu_baseline(sd, L, not args.cpu_short)
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(res) + "\n").encode())
     if dist.is_initialized():

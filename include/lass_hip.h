@@ -43,7 +43,8 @@ typedef struct lass_ctx lass_ctx;
 #define LASS_I64 1
 
 /* compute modes for lass_finalize */
-#define LASS_COMPUTE_F32 0     /* f32 storage, f32 MFMA contractions (plain f32 FMAs; Winograd F(2x2,3x3) for even H) */
+#define LASS_COMPUTE_F32 0     /* f32 storage, f32 MFMA contractions (plain f32 FMAs): Winograd F(4x4,3x3) for the 3x3 convs with
+                                  >= 64 input channels at >= 32-bin resolutions (LASS_WINO4=0: none), F(2x2,3x3) for the rest */
 #define LASS_COMPUTE_BF16 1    /* convolutions contracted on the bf16 MFMA (operands rounded to bf16, f32 accumulate):
                                   BASELINE configs[2].  Inside the workspace the tensors handed from one conv launch to
                                   the next (block intermediates, decoder concats, pooled encoder outputs, transposed-conv
@@ -57,7 +58,11 @@ typedef struct lass_ctx lass_ctx;
 int lass_version(void);
 
 /* Create a context on HIP device `device_id`.  Builds the FFT twiddle / Hann tables.
- * Replaces: ResUNet30.__init__ (resunet.py:621-637) + torchlibrosa STFT/ISTFT construction (:284-302). */
+ * Replaces: ResUNet30.__init__ (resunet.py:621-637) + torchlibrosa STFT/ISTFT construction (:284-302).
+ * LIMIT: the context implements ResUNet30(input_channels=1, output_channels=1, condition_size=512) with
+ * target_sources_num = 1 - the only configuration the reference ships (config/audiosep_base.yaml:23-30); resunet.py:425-470,
+ * 621-637 is written for target_sources_num x output_channels x 3 mask channels, and the Python mirror raises
+ * NotImplementedError for anything else (lass_amd/resunet.py). */
 int lass_create(lass_ctx** out, int device_id);
 /* Context for the multi-resolution-STFT separator (BASELINE configs[4]; reference intent:
  * models/resunet_with_multistft.py:40-118,137-216 - not runnable as shipped, see DESIGN.md section 9 for the authored
@@ -105,6 +110,9 @@ int lass_separate(lass_ctx* ctx, const float* mixture, const float* condition, f
  * after it, too, has been seen three times in a row).  Nothing else about the call changes; profiled
  * contexts and LASS_GRAPH=0 stay eager.  Returns 1 if replay is enabled, 0 if not; counters are optional outputs. */
 int lass_graph_stats(const lass_ctx* ctx, long* captures, long* replays);
+/* Turns graph replay off (0: every call launches its kernels eagerly) or back on (cached graphs are replayed again).
+ * A measurement switch - bench.py times both forms of the same step - with no effect on results. */
+int lass_set_graph_replay(lass_ctx* ctx, int enabled);
 
 /* The same path from a PRECOMPUTED analysis of the mixtures, as the reference's multi-STFT wrapper takes it
  * (resunet_with_multistft.py:233-241: input_dict["stft_mixture_mag" / "_cos" / "_sin"][win]; producer:

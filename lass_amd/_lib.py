@@ -27,6 +27,7 @@ SYMBOLS = [
     ("lass_multi_stft", c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, POINTER(c_int), POINTER(c_void_p),
                                 POINTER(c_void_p), POINTER(c_void_p), c_void_p]),
     ("lass_graph_stats", c_int, [c_void_p, POINTER(c_long), POINTER(c_long)]),
+    ("lass_set_graph_replay", c_int, [c_void_p, c_int]),
     ("lass_separate_components", c_int, [c_void_p, POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                          c_int, c_void_p, c_size_t, c_void_p]),
     ("lass_stft_components", c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, POINTER(c_int),

@@ -172,6 +172,31 @@ def conv_layer_table(t_pad: int, f: int = F_CROP) -> List[Dict]:
     return rows
 
 
+def wino4_routed(rows: List[Dict], min_cin: int = 64) -> set:
+    """Names of the 3x3 rows of `conv_layer_table` that the f32 path runs as Winograd F(4x4,3x3) (csrc/wino4.hip; 36 instead
+    of 144 MFMA multiplies per 4x4 output tile and (cin, cout) pair) - a mirror of the dispatch in csrc/api.hip
+    (run_resblock) and lass_wino4_supported: at least `min_cin` input channels (LASS_WINO4, default 64; 0 = none), images
+    whose width is a multiple of 32 and that tile into 8 x 64 or 16 x 32 pixel blocks; conv1 of every block but
+    encoder_block1 (its input is formed from x0 while staging: wino32.hip), conv2 of the blocks with a 1x1 shortcut but
+    decoder_block6 (fused output head: wino32.hip)."""
+    if min_cin <= 0:
+        return set()
+    with_shortcut = {r["name"].rsplit(".", 1)[0] for r in rows if r["name"].endswith(".shortcut")}
+    out = set()
+    for r in rows:
+        if r["kind"] != "3x3":
+            continue
+        block, conv = r["name"].rsplit(".", 1)
+        geom = r["w"] % 32 == 0 and ((r["w"] % 64 == 0 and r["h"] % 8 == 0) or r["h"] % 16 == 0)
+        if not (geom and r["cin"] >= min_cin and r["cin"] % 8 == 0 and r["cout"] % 32 == 0):
+            continue
+        if conv == "conv1" and block != "encoder_block1":
+            out.add(r["name"])
+        if conv == "conv2" and block in with_shortcut and block != "decoder_block6":
+            out.add(r["name"])
+    return out
+
+
 def conv_macs_per_clip(length: int) -> int:
     return sum(r["macs"] for r in conv_layer_table(padded_frames(frames_for(length))))
 

@@ -131,6 +131,7 @@ struct lass_ctx {
     struct GraphEntry {
         GraphKey key;
         hipGraphExec_t exec = nullptr;
+        size_t need = 0;         // workspace bytes the captured plan addresses (re-checked on every replay)
         int seen = 0;            // calls with this key so far
         unsigned long used = 0;  // g_tick of the last call (LRU)
     };
@@ -1421,19 +1422,40 @@ int lass_separate(lass_ctx* c, const float* mixture, const float* condition, flo
         if (!slot) {  // take the least recently used slot, preferring one without a graph
             for (auto& e : c->g_slots)
                 if (!slot || (!e.exec && slot->exec) || (!e.exec == !slot->exec && e.used < slot->used)) slot = &e;
-            if (slot->exec) c->g_retired.push_back(slot->exec);  // may still be replaying: destroyed behind a device sync
+            if (slot->exec) {  // may still be replaying on some stream: destroyed only behind a device synchronisation
+                c->g_retired.push_back(slot->exec);
+                if (c->g_retired.size() > 8) {  // a caller cycling through many recurring keys: bound the list here
+                    HIP_TRY(c, hipSetDevice(c->device));
+                    HIP_TRY(c, hipDeviceSynchronize());
+                    for (hipGraphExec_t x : c->g_retired) (void)hipGraphExecDestroy(x);
+                    c->g_retired.clear();
+                }
+            }
             *slot = lass_ctx::GraphEntry();
             slot->key = key;
         }
         slot->used = c->g_tick;
         ++slot->seen;
         if (slot->exec) {
+            if (workspace_bytes < slot->need)
+                return fail(c, LASS_ERR_WORKSPACE, "workspace too small: need " + std::to_string(slot->need) + " bytes");
             HIP_TRY(c, hipSetDevice(c->device));
             HIP_TRY(c, hipGraphLaunch(slot->exec, (hipStream_t)stream));
             ++c->g_replays;
             return 0;
         }
         if (slot->seen >= 3) {  // worth a capture
+            // argument errors are reported as such, before any capture starts: only a failure of the capture machinery
+            // itself (begin / end / instantiate, or a launch refused under capture) turns graph replay off
+            {
+                int r0 = check_ready(c);
+                if (r0) return r0;
+                Plan pl0;
+                if (!condition || !out || !workspace || make_plan(c, B, L, &pl0) || workspace_bytes < pl0.total ||
+                    ((uintptr_t)workspace & 255) != 0)
+                    return separate_impl(c, mixture, nullptr, condition, out, B, L, workspace, workspace_bytes, stream, "lass_separate");
+                slot->need = pl0.total;
+            }
             HIP_TRY(c, hipSetDevice(c->device));
             if (!c->g_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->g_stream, hipStreamNonBlocking));
             bool ok = false;
@@ -1461,6 +1483,12 @@ int lass_separate(lass_ctx* c, const float* mixture, const float* condition, flo
         }
     }
     return separate_impl(c, mixture, nullptr, condition, out, B, L, workspace, workspace_bytes, stream, "lass_separate");
+}
+
+int lass_set_graph_replay(lass_ctx* c, int enabled) {
+    if (!c) return LASS_ERR_ARG;
+    c->use_graph = enabled != 0;  // captured graphs stay cached: switching back on replays them again
+    return 0;
 }
 
 int lass_graph_stats(const lass_ctx* c, long* captures, long* replays) {

@@ -304,8 +304,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_kernel(ConvArgs p) {
                 const unsigned soff = PRE ? 0u : (unsigned)((ch * KC + it * CSTEP) * HW) * 4u;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    ps[BUF][it][2 * i] = __builtin_bit_cast(f2u, __builtin_amdgcn_raw_buffer_load_b64(in_rsrc, (int)voa[i], (int)soff, 0));
-                    ps[BUF][it][2 * i + 1] = __builtin_bit_cast(f2u, __builtin_amdgcn_raw_buffer_load_b64(in_rsrc, (int)vob[i], (int)soff, 0));
+                    // (PRE: one patch set, loaded once - the BUF = 1 instantiation is never called but is compiled)
+                    ps[PRE ? 0 : BUF][it][2 * i] = __builtin_bit_cast(f2u, __builtin_amdgcn_raw_buffer_load_b64(in_rsrc, (int)voa[i], (int)soff, 0));
+                    ps[PRE ? 0 : BUF][it][2 * i + 1] = __builtin_bit_cast(f2u, __builtin_amdgcn_raw_buffer_load_b64(in_rsrc, (int)vob[i], (int)soff, 0));
                 }
             }
         };

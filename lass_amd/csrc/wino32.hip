@@ -38,9 +38,13 @@ constexpr int NW32 = 8;           // waves per workgroup: two per SIMD, one work
 #ifndef W32_EXP
 #define W32_EXP 0
 #endif
-// Every MFMA statement opens with two wait states: a vector instruction that wrote one of its A / B operands may sit right
-// in front of it, and hipcc pads nothing for an instruction it cannot see (without them decoder_block6's shortcut phase
-// came out wrong in the xi = 0 accumulators, differently from run to run; cdna_hip_programming.md 5.7 item 2).
+// Every MFMA statement opens with two wait states.  Cause (round 4, established in the ISA): on gfx950 an MFMA must sit at
+// least two wait states behind a vector instruction that wrote one of its source operands; hipcc pads that for its builtin
+// MFMAs (tools/mfma_operand_hazard.hip: v_mul, s_waitcnt, s_nop 0, v_mfma) and pads nothing for an asm statement.  Without the
+// s_nop the K loop's FIRST statement follows the input transform directly - `v_sub_f32 v0, v0, v12` then
+// `v_mfma_f32_16x16x4_f32 v[108:111], v4, v0, 0` in decoder_block6's kernel - and reads a stale B operand into the xi = 0
+// accumulators: round 3's run-to-run wrong results.  tools/audit_wino32_isa.py checks the two wait states for every MFMA of
+// the shipped ISA and fails on the s_nop-less build (tests/test_host_cpu.py::test_wino32_isa_audit).
 #ifndef W32_NOP
 #define W32_NOP "s_nop 1\n\t"
 #endif
@@ -536,11 +540,17 @@ __global__ __launch_bounds__(256) void wino32_shortcut_weights_kernel(const floa
 
 template <int FLAGS, int CIN, int CIN2>
 hipError_t launch32(const ConvArgs& p, hipStream_t stream) {
-    static const int ncu = [] {
-        int dev = 0, n = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-        return n > 0 ? n : 256;
-    }();
+    // CUs of the CURRENT device (lass_separate runs under hipSetDevice(ctx->device)); cached per device, not per process
+    static int ncu_of[64] = {0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int& cached = ncu_of[dev & 63];
+    if (cached <= 0) {
+        int n = 0;
+        (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        cached = n > 0 ? n : 256;
+    }
+    const int ncu = cached;
     const long ns = p.N / 32;  // 32-cout slices: a workgroup serves one of them
     const long nblk = (long)(p.W / 32) * ((p.H / 2 + NW32 - 1) / NW32) * p.B * ns;
     // persistent: one workgroup per CU, every wave's loop is bounded; a multiple of the slice count

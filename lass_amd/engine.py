@@ -332,6 +332,10 @@ class Engine:
         on = self.lib.lass_graph_stats(self.ctx, byref(cap), byref(rep))
         return bool(on), cap.value, rep.value
 
+    def set_graph_replay(self, on: bool):
+        """hipGraph replay of lass_separate on / off (off: every call launches eagerly; a measurement switch)."""
+        _lib.check(self.ctx, self.lib.lass_set_graph_replay(self.ctx, 1 if on else 0), "lass_set_graph_replay")
+
     # ---- instrumentation -------------------------------------------------------------------------------------
     def set_profiling(self, on: bool):
         self.lib.lass_set_profiling(self.ctx, 1 if on else 0)

@@ -174,6 +174,24 @@ class PrecomputedSTFTDataset(torch.utils.data.Dataset):
     def shard_sizes(self) -> List[int]:
         return [sh.count for sh in self._shards]
 
+    # read-only mirrors of the reference class's public attributes (data/precomputed_stft_dataset.py:27-29,62)
+    @property
+    def file_paths(self) -> List[pathlib.Path]:
+        return [sh.path for sh in self._shards]
+
+    @property
+    def item_counts(self) -> List[int]:
+        return [sh.count for sh in self._shards]
+
+    @property
+    def cumulative_counts(self) -> List[int]:
+        """cumulative_counts[i] = items before shard i; one trailing entry = the total (as the reference keeps it)."""
+        return [sh.first for sh in self._shards] + [self._size]
+
+    @property
+    def total_items(self) -> int:
+        return self._size
+
     def __len__(self) -> int:
         return self._size
 

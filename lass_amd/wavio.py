@@ -1,9 +1,12 @@
 """Minimal RIFF/WAVE reader-writer (PCM16, PCM32, float32), mono down-mix.
 
 Stands in for `librosa.load(path, sr=16000, mono=True)` (dcase_evaluator.py:73-74) for files that are ALREADY at the
-target rate: the DCASE validation audio is distributed at 16 kHz mono (scripts/process_audio.sh: `sox -r 16000 -c 1`),
-so the load reduces to PCM decode + int->float scaling (x/32768 for int16, as soundfile/librosa do).  Resampling is
-not implemented - a rate mismatch raises.
+target rate: the load then reduces to PCM decode + mono down-mix + int->float scaling (x/32768 for int16, as
+soundfile/librosa do).  Whether the Zenodo validation audio is at 16 kHz is NOT established from the reference (its
+scripts/process_audio.sh converts TRAINING data with `sox -r 16000 -c 1`; the validation set's rate is not stated):
+`librosa.load` would resample such files (soxr/`kaiser_best`; librosa is absent here, so any resampler written in its
+place would be parity-unpinned) - this reader raises on a rate mismatch instead of guessing, and the caller resamples
+offline (e.g. the same `sox -r 16000 -c 1`).
 """
 from __future__ import annotations
 
