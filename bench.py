@@ -359,7 +359,7 @@ def main():
 
     rows = arch.conv_layer_table(arch.padded_frames(arch.frames_for(L)))
     wino = os.environ.get("LASS_WINO", "1") != "0"
-    w4thr = int(os.environ.get("LASS_WINO4", "64"))
+    w4thr = int(os.environ.get("LASS_WINO4", "32"))
     w4rows = arch.wino4_routed(rows, w4thr) if wino else set()
 
     def mode_record(dtype, dt_mode, steps, prof_mode):
@@ -492,7 +492,7 @@ def main():
         traffic = traffic_fields(args.dtype, alg_bytes_launch_of(head), (B, L) == (16, 160000))
         alg_bytes_launch = alg_bytes_launch_of(head)
         kernel = {"f32": (f"wino4_kernel<...> x{len(w4rows)} (Winograd F(4x4,3x3): {', '.join(sorted(w4rows))}) + wino32_kernel / "
-                          f"wino_kernel x{26 - len(w4rows)} (F(2x2,3x3): the 32-cout full-resolution and the 16-/8-bin layers) on "
+                          f"wino_kernel x{26 - len(w4rows)} (F(2x2,3x3): the 16-/8-bin layers) on "
                           "v_mfma_f32_16x16x4_f32, 1x1 shortcuts fused (conv3x3_mfma class)") if wino else "conv_kernel (direct f32 MFMA)",
                   "bf16": "conv_bf16_kernel x22 + enc1_fused / dec6u_fused_bf16_kernel (a ConvBlockRes each, decoder_block6's with its "
                           "transposed conv inside): direct 3x3 + fused 1x1 shortcuts on v_mfma_f32_32x32x16_bf16",

@@ -172,13 +172,13 @@ def conv_layer_table(t_pad: int, f: int = F_CROP) -> List[Dict]:
     return rows
 
 
-def wino4_routed(rows: List[Dict], min_cin: int = 64) -> set:
+def wino4_routed(rows: List[Dict], min_cin: int = 32) -> set:
     """Names of the 3x3 rows of `conv_layer_table` that the f32 path runs as Winograd F(4x4,3x3) (csrc/wino4.hip; 36 instead
     of 144 MFMA multiplies per 4x4 output tile and (cin, cout) pair) - a mirror of the dispatch in csrc/api.hip
-    (run_resblock) and lass_wino4_supported: at least `min_cin` input channels (LASS_WINO4, default 64; 0 = none), images
-    whose width is a multiple of 32 and that tile into 8 x 64 or 16 x 32 pixel blocks; conv1 of every block but
-    encoder_block1 (its input is formed from x0 while staging: wino32.hip), conv2 of the blocks with a 1x1 shortcut but
-    decoder_block6 (fused output head: wino32.hip)."""
+    (run_resblock) and lass_wino4_supported: at least `min_cin` input channels (LASS_WINO4, default 32; 0 = none), images
+    whose width is a multiple of 32 and that tile into 8 x 64 or 16 x 32 pixel blocks; conv1 of every block, conv2 of the
+    blocks with a 1x1 shortcut (decoder_block6's with the fused output head) and of encoder_block1 (residual = pre_conv(x0)).
+    The identity blocks at 16 / 8 bins (encoder_block6, conv_block7a) and decoder_block1/2's narrow levels stay F(2x2,3x3)."""
     if min_cin <= 0:
         return set()
     with_shortcut = {r["name"].rsplit(".", 1)[0] for r in rows if r["name"].endswith(".shortcut")}
@@ -190,9 +190,9 @@ def wino4_routed(rows: List[Dict], min_cin: int = 64) -> set:
         geom = r["w"] % 32 == 0 and ((r["w"] % 64 == 0 and r["h"] % 8 == 0) or r["h"] % 16 == 0)
         if not (geom and r["cin"] >= min_cin and r["cin"] % 8 == 0 and r["cout"] % 32 == 0):
             continue
-        if conv == "conv1" and block != "encoder_block1":
+        if conv == "conv1":
             out.add(r["name"])
-        if conv == "conv2" and block in with_shortcut and block != "decoder_block6":
+        if conv == "conv2" and (block in with_shortcut or block.startswith("encoder_block1")):
             out.add(r["name"])
     return out
 

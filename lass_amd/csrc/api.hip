@@ -105,7 +105,7 @@ struct lass_ctx {
     // profiling
     int compute_mode = LASS_COMPUTE_F32;
     bool wino = true;          // Winograd F(2x2,3x3) kernels for the 3x3 convs at W >= 32 (LASS_WINO=0: direct only)
-    int wino4_mincin = 64;     // 3x3 convs with at least that many input channels (and >= 32-wide images) run as Winograd
+    int wino4_mincin = 32;     // 3x3 convs with at least that many input channels (and >= 32-wide images) run as Winograd
                                // F(4x4,3x3) (wino4.hip); LASS_WINO4=<min Cin>, 0 = off (F(2x2,3x3) everywhere)
     bool wino32 = true;        // weights-resident persistent kernel for the 32-cout layers (LASS_WINO32=0: wino.hip everywhere)
     bool fuse_preconv = true;  // LASS_FUSE_PRECONV=0 materialises pre_conv's output with its own kernel
@@ -445,8 +445,8 @@ int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int
         ProfScope ps(c, st, P_CONV3X3);
         if (bf1)
             HIP_TRY(c, lass_launch_conv_bf16(x0 ? CONV1_ACT_PRE : CONV1_ACT, p, st));
-        else if (wino1 && !x0 && rb.u1f && lass_wino4_supported(CONV1_ACT, p))
-            HIP_TRY(c, lass_launch_wino4(CONV1_ACT, p, st));
+        else if (wino1 && rb.u1f && lass_wino4_supported(x0 ? CONV1_ACT_PRE : CONV1_ACT, p))
+            HIP_TRY(c, lass_launch_wino4(x0 ? CONV1_ACT_PRE : CONV1_ACT, p, st));
         else if (wino1 && c->wino32 && lass_wino32_supported(x0 ? CONV1_ACT_PRE : CONV1_ACT, p))
             HIP_TRY(c, lass_launch_wino32(x0 ? CONV1_ACT_PRE : CONV1_ACT, p, st));
         else if (wino1)
@@ -530,6 +530,8 @@ int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int
     if (rb.cin == rb.cout) {
         if (bf2)
             HIP_TRY(c, lass_launch_conv_bf16(x0 ? CONV2_IDENT_PRE : CONV2_IDENT, q, st));
+        else if (wino2 && x0 && rb.u2f && lass_wino4_supported(CONV2_IDENT_PRE, q))
+            HIP_TRY(c, lass_launch_wino4(CONV2_IDENT_PRE, q, st));
         else if (wino2 && c->wino32 && lass_wino32_supported(x0 ? CONV2_IDENT_PRE : CONV2_IDENT, q))
             HIP_TRY(c, lass_launch_wino32(x0 ? CONV2_IDENT_PRE : CONV2_IDENT, q, st));
         else if (wino2)
@@ -895,7 +897,10 @@ int lass_finalize(lass_ctx* c, int compute_mode) {
                 if (dev_alloc(c, &rb.u1f, (size_t)36 * rb.cout * rb.cin)) return LASS_ERR_HIP;
                 HIP_TRY(c, lass_launch_wino4_weights(w1, rb.cout, rb.cin, rb.u1f, st));
             }
-            if (c->wino4_mincin > 0 && rb.cout >= c->wino4_mincin && rb.cin != rb.cout && rb.cout % 32 == 0 && rb.cin % 8 == 0) {
+            // conv2: the blocks with a 1x1 shortcut, and encoder_block1 (32 -> 32, residual = pre_conv(x0)); the identity blocks
+            // at the bottom of the U-Net (16 / 8 bins) stay with wino.hip
+            if (c->wino4_mincin > 0 && rb.cout >= c->wino4_mincin && (rb.cin != rb.cout || rb.cout == kPreCh) && rb.cout % 32 == 0 &&
+                rb.cin % 8 == 0) {
                 if (dev_alloc(c, &rb.u2f, (size_t)36 * rb.cout * rb.cout)) return LASS_ERR_HIP;
                 HIP_TRY(c, lass_launch_wino4_weights(w2, rb.cout, rb.cout, rb.u2f, st));
             }

@@ -29,7 +29,7 @@
 
 namespace {
 
-constexpr int F_PRO = 1, F_PHASEB = 2, F_BIAS = 4, F_EPIACT = 16;  // as wino.hip
+constexpr int F_PRO = 1, F_PHASEB = 2, F_BIAS = 4, F_RES = 8, F_EPIACT = 16, F_PRECONV = 64, F_RESPRE = 128, F_MASK = 1024;  // as wino.hip
 constexpr int NTHREADS = 256;
 constexpr int KC = 8;
 constexpr int NXI = 36;
@@ -65,14 +65,21 @@ __device__ __forceinline__ void at6(const float (&m)[6], float (&y)[4]) {
 template <int TC, int FLAGS>
 __global__ __launch_bounds__(NTHREADS, 2) void wino4_kernel(ConvArgs p) {
     constexpr bool PRO = (FLAGS & F_PRO) != 0, EPI = (FLAGS & F_EPIACT) != 0, SC = (FLAGS & F_PHASEB) != 0;
+    constexpr bool PRE = (FLAGS & F_PRECONV) != 0;   // the input is the 1-channel x0: channel c = pre_w[c] * x0 + pre_b[c] (resunet.py:555)
+    constexpr bool RESPRE = (FLAGS & F_RESPRE) != 0; // identity residual = pre_conv(x0), never materialised (encoder_block1.conv2)
+    constexpr bool MASK = (FLAGS & F_MASK) != 0;     // epilogue = after_conv + complex ratio mask; the block output is not written
     static_assert(!SC || (FLAGS & F_BIAS) != 0, "the shortcut conv has a bias");
+    static_assert(!PRE || PRO, "pre_conv is folded into the prologue's affine");
+    static_assert(!RESPRE || ((FLAGS & F_RES) != 0 && !SC && !EPI), "conv2 with the identity residual");
+    static_assert(!MASK || SC, "the output head sits behind decoder_block6's conv2 + shortcut");
     constexpr int TR = 32 / TC;
     constexpr int OR_ = 4 * TR, OC = 4 * TC;
-    __shared__ __attribute__((aligned(16))) float lds[U_F + V_F + 64];
+    __shared__ __attribute__((aligned(16))) float lds[U_F + V_F + 64 + (MASK ? 100 : 0)];
     float* lu = lds;
     float* lv = lds + U_F;
     float* lds_es = lv + V_F;
     float* lds_eh = lds_es + 32;
+    float* lds_mw = lds_eh + 32;  // MASK: after_conv weight [3][32] + bias [3]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -92,6 +99,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino4_kernel(ConvArgs p) {
         lds_eh[tid] = p.epi_shift[(size_t)b * p.epi_shift_bs + n0 + tid];
     }
     if (SC && tid < 32) lds_es[tid] = p.bias[n0 + tid];  // (SC and EPI exclude each other: one table)
+    if (RESPRE && tid < 32) {                               // residual affine of this block's 32 output channels
+        lds_es[tid] = p.pre_w[n0 + tid];
+        lds_eh[tid] = p.pre_b[n0 + tid];
+    }
+    if (MASK && tid < 99) lds_mw[tid] = tid < 96 ? p.mask_w[tid] : p.mask_b[tid - 96];
 
     f32x4 acc[NXI];
 #pragma unroll
@@ -118,19 +130,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino4_kernel(ConvArgs p) {
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         const int gy = gy0 + i;
-        const int row = c8 * HW + min(max(gy, 0), p.H - 1) * p.W;
+        const int row = (PRE ? 0 : c8 * HW) + min(max(gy, 0), p.H - 1) * p.W;
         vo_c[i] = 4u * (unsigned)(row + gx0 + 1);                 // columns gx0+1 .. gx0+4: 16-byte aligned, always inside
         vo_l[i] = 4u * (unsigned)(row + (left ? 0 : gx0));        // column gx0 (clamped at the left edge)
         vo_r[i] = 4u * (unsigned)(row + (right ? p.W - 1 : gx0 + 5));
         rowok |= (gy >= 0 && gy < p.H ? 1u : 0u) << i;
     }
     const __amdgpu_buffer_rsrc_t in_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_b), 0, (int)((unsigned)p.Cin * (unsigned)HW * 4u), 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_b), 0, (int)((unsigned)(PRE ? 1 : p.Cin) * (unsigned)HW * 4u), 0x00020000);
     const bool edge = left || right || rowok != 0x3fu;  // this item's patch reaches into the zero padding
     float4 pc[6];
     float pl[6], pr[6], ps = 1.f, ph = 0.f;
     auto pload = [&](int ch) {
-        const unsigned soff = (unsigned)(ch * KC * HW) * 4u;
+        const unsigned soff = PRE ? 0u : (unsigned)(ch * KC * HW) * 4u;
+        if (!PRE || ch == 0)  // PRE: every channel is an affine function of the one x0 patch, loaded once
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             pc[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (int)vo_c[i], (int)soff, 0));
@@ -141,8 +154,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino4_kernel(ConvArgs p) {
             ps = sc[ch * KC + c8];
             ph = sh[ch * KC + c8];
         }
+        if (PRE) {  // leaky(bn(pre_w x0 + pre_b) + beta) = leaky(x0 * (pre_w s) + (pre_b s + h))
+            const float pw = p.pre_w[ch * KC + c8], pb = p.pre_b[ch * KC + c8];
+            ph = fmaf(pb, ps, ph);
+            ps = pw * ps;
+        }
     };
-    constexpr int NLOAD = 6 * 3 + (PRO ? 2 : 0);  // vector-memory operations of one pload
+    constexpr int NLOAD = (PRE ? 0 : 6 * 3) + (PRO ? 2 : 0) + (PRE ? 2 : 0);  // vector-memory operations of one pload (chunks >= 1)
     // V destination of this item: row (xi, kq = c8 % 4), column tile ^ swizzle, k-step c8 / 4; xi stride = 4 * 64 floats
     float* vdst = lv + ((c8 & 3) * 32 + (pt ^ ((c8 & 1) << 4))) * 2 + (c8 >> 2);
     auto pprocess = [&]() {
@@ -277,6 +295,23 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino4_kernel(ConvArgs p) {
             }
         }
     }
+    if constexpr (RESPRE) {  // + pre_conv(x0) at this lane's 16 pixels (resunet.py:555,165)
+        const float* xr = p.res + (size_t)b * p.res_bs + (size_t)min(oy, p.H - 4) * p.W + ox;
+        float4 xv[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) xv[a] = *reinterpret_cast<const float4*>(xr + (size_t)a * p.W);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float pw = lds_es[wco * 16 + kq * 4 + r], pb = lds_eh[wco * 16 + kq * 4 + r];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                ysp[a * 4 + 0][r] += fmaf(xv[a].x, pw, pb);
+                ysp[a * 4 + 1][r] += fmaf(xv[a].y, pw, pb);
+                ysp[a * 4 + 2][r] += fmaf(xv[a].z, pw, pb);
+                ysp[a * 4 + 3][r] += fmaf(xv[a].w, pw, pb);
+            }
+        }
+    }
     if constexpr (SC) {
         // ---- 1x1 shortcut over the raw block input (resunet.py:163), direct: per 4 input channels 16 MFMAs, one per sub-pixel;
         // B[k = kq][col = l15] = x[channel 4 ks + kq][this lane's tile, sub-pixel s] (four 16-byte row loads),
@@ -284,8 +319,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino4_kernel(ConvArgs p) {
         const float* x2 = p.in2 + (size_t)b * p.in2_bs + (size_t)min(oy, p.H - 4) * p.W + ox;
         const float* wsc = p.w2 + n0 + wco * 16 + l15;  // [Cin2][Nw]
         const int nks = p.Cin2 / 4;
-        float4 xb[2][4];
-        float wa[2];
+        // operands of the next THREE k-steps are in flight behind the 16 MFMAs of the current one (512 cycles: less than one
+        // L2 round trip under load); the accumulators of the main phase are dead here, registers are free
+        constexpr int NSB = 4;
+        float4 xb[NSB][4];
+        float wa[NSB];
         auto ldk = [&](int ks, int buf) {
             const float* xp = x2 + (size_t)(4 * ks + kq) * HW;
 #pragma unroll
@@ -302,16 +340,63 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino4_kernel(ConvArgs p) {
             }
         };
         ldk(0, 0);
-        for (int ks = 0; ks < nks; ks += 2) {  // Cin2 % 8 == 0 (host-checked)
-            ldk(ks + 1, 1);
-            __builtin_amdgcn_sched_barrier(0);
-            mmk(0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (ks + 2 < nks) ldk(ks + 2, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            mmk(1);
-            __builtin_amdgcn_sched_barrier(0);
+        ldk(1, 1);
+        ldk(2, 2);
+        for (int ks = 0; ks < nks; ks += NSB) {  // Cin2 % 16 == 0 (host-checked): whole groups of NSB k-steps
+#pragma unroll
+            for (int u = 0; u < NSB; ++u) {
+                ldk(min(ks + u + 3, nks - 1), (u + 3) % NSB);  // (behind the end: the last k-step again, unused)
+                __builtin_amdgcn_sched_barrier(0);
+                mmk(u);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
+    }
+    if constexpr (MASK) {
+        // ---- fused output head (resunet.py:570-574,436-519): after_conv needs all 32 channels of a pixel; they sit in the 4 kq
+        // lane groups of the 2 cout waves.  Every lane forms its partial logits (3 x 16 pixels over its 4 channels) and leaves
+        // them in the dead U / V region, [source = wco * 4 + kq][logit][pixel = tile * 16 + s]; then every thread finishes 2 pixels.
+        float* part = lds;  // 8 * 3 * 512 floats = 48 KiB <= U_F + V_F
+        lds_barrier();      // every wave is past its last MFMA phase
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            float w4[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) w4[r] = lds_mw[q * 32 + wco * 16 + kq * 4 + r];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                float4 o;
+                float* op = &o.x;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const f32x4 v = ysp[a * 4 + c];
+                    op[c] = v[0] * w4[0] + v[1] * w4[1] + v[2] * w4[2] + v[3] * w4[3];
+                }
+                *reinterpret_cast<float4*>(part + ((wco * 4 + kq) * 3 + q) * 512 + ot * 16 + a * 4) = o;
+            }
+        }
+        lds_barrier();
+        const int px = tid * 2;  // pixels px, px + 1: same tile, same row
+        const int mt = px >> 4, ms = px & 15;
+        const int my = y0 + 4 * (mt / TC) + (ms >> 2), mx = x0 + 4 * (mt % TC) + (ms & 3);
+        float lg[3][2];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            float2 sum = make_float2(lds_mw[96 + q], lds_mw[96 + q]);
+#pragma unroll
+            for (int src = 0; src < 8; ++src) {
+                const float2 v = *reinterpret_cast<const float2*>(part + (src * 3 + q) * 512 + px);
+                sum.x += v.x;
+                sum.y += v.y;
+            }
+            lg[q][0] = sum.x;
+            lg[q][1] = sum.y;
+        }
+        if (my < p.mask_T) {
+            mask_pixel(p, b, my, mx, lg[0][0], lg[1][0], lg[2][0]);
+            mask_pixel(p, b, my, mx + 1, lg[0][1], lg[1][1], lg[2][1]);
+        }
+        return;
     }
     // ---- stores: 16-byte rows; the block's 2x2 avg-pool (resunet.py:197) from the same registers -----------------------------
 #pragma unroll
@@ -323,7 +408,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino4_kernel(ConvArgs p) {
             const float4 o = make_float4(ysp[a * 4 + 0][r], ysp[a * 4 + 1][r], ysp[a * 4 + 2][r], ysp[a * 4 + 3][r]);
             if (oy + a < p.H) *reinterpret_cast<float4*>(dst + (size_t)a * p.W) = o;
         }
-        if (SC && p.pool_out) {  // wave-uniform; pool_h == 2 (host-checked): row-major summation order of F.avg_pool2d
+        if ((SC || RESPRE) && p.pool_out) {  // wave-uniform; pool_h == 2 (host-checked): row-major summation order of F.avg_pool2d
             const int Ho = p.H / 2, Wo = p.W / 2;
             float* pd = p.pool_out + (size_t)b * (p.pool_bs ? (size_t)p.pool_bs : (size_t)p.N * Ho * Wo) + (size_t)n * Ho * Wo +
                         (size_t)(oy >> 1) * Wo + (ox >> 1);
@@ -391,18 +476,38 @@ bool lass_wino4_supported(ConvKind kind, const ConvArgs& p) {
     if (!(p.w_wino4 && ((p.W % 64 == 0 && p.H % 8 == 0) || (p.W % 32 == 0 && p.H % 16 == 0)) && p.Cin % KC == 0 && p.N % 32 == 0 &&
           p.Nw % 32 == 0 && (unsigned long long)p.Cin * p.H * p.W * 4ull < 0xFFFF0000ull))
         return false;
-    if (kind == CONV1_ACT) return true;
-    // conv2 + 1x1 shortcut (+ fused 2x2 avg-pool); the fused output head stays with wino32.hip / wino.hip
-    return kind == CONV2_SHORTCUT && !p.mask_re && p.in2 && p.w2 && p.bias && p.Cin2 % 8 == 0 && (!p.pool_out || p.pool_h == 2);
+    switch (kind) {
+        case CONV1_ACT:
+            return true;
+        case CONV1_ACT_PRE:  // encoder_block1.conv1: the 32 input channels are formed from x0
+            return p.pre_w && p.pre_b && p.Cin == 32;
+        case CONV2_IDENT_PRE:  // encoder_block1.conv2: residual = pre_conv(x0), fused 2x2 avg-pool
+            return p.res && p.pre_w && p.pre_b && p.N == 32 && p.Nw == 32 && (!p.pool_out || p.pool_h == 2);
+        case CONV2_SHORTCUT:  // conv2 + 1x1 shortcut (+ fused 2x2 avg-pool, or decoder_block6's fused output head)
+            if (!(p.in2 && p.w2 && p.bias && p.Cin2 % 16 == 0 && (!p.pool_out || p.pool_h == 2))) return false;
+            if (p.mask_re)
+                return p.N == 32 && p.Nw == 32 && p.W + 1 == p.mask_nbins && p.mask_w && p.mask_b && p.mask_mag && p.mask_cos && p.mask_sin &&
+                       p.mask_im && p.mask_T > 0 && p.mask_T <= p.H && !p.pool_out;
+            return true;
+        default:
+            return false;
+    }
 }
 
 hipError_t lass_launch_wino4(ConvKind kind, const ConvArgs& p, hipStream_t stream) {
-    if (!lass_wino4_supported(kind, p) || !p.in || !p.out) return hipErrorInvalidValue;
-    if (kind == CONV1_ACT) {
-        if (!p.pro_scale || !p.pro_shift || !p.epi_scale || !p.epi_shift) return hipErrorInvalidValue;
-        return launch_wino4<F_PRO | F_EPIACT>(p, stream);
+    if (!lass_wino4_supported(kind, p) || !p.in || (!p.out && !p.mask_re)) return hipErrorInvalidValue;
+    switch (kind) {
+        case CONV1_ACT:
+        case CONV1_ACT_PRE:
+            if (!p.pro_scale || !p.pro_shift || !p.epi_scale || !p.epi_shift) return hipErrorInvalidValue;
+            return kind == CONV1_ACT ? launch_wino4<F_PRO | F_EPIACT>(p, stream) : launch_wino4<F_PRO | F_EPIACT | F_PRECONV>(p, stream);
+        case CONV2_IDENT_PRE:
+            return launch_wino4<F_RES | F_RESPRE>(p, stream);
+        case CONV2_SHORTCUT:
+            return p.mask_re ? launch_wino4<F_PHASEB | F_BIAS | F_MASK>(p, stream) : launch_wino4<F_PHASEB | F_BIAS>(p, stream);
+        default:
+            return hipErrorInvalidValue;
     }
-    return launch_wino4<F_PHASEB | F_BIAS>(p, stream);
 }
 
 hipError_t lass_launch_wino4_weights(const float* w, int Cout, int Cin, float* U, hipStream_t stream) {

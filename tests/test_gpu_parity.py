@@ -457,7 +457,8 @@ def test_fusion_switches_agree(synthetic_sd, monkeypatch):
     scale = float(ref.pow(2).mean().sqrt())
     for env in ({"LASS_FUSE_MASK": "0"}, {"LASS_FUSE_POOL": "0", "LASS_FUSE_PRECONV": "0"}, {"LASS_WINO": "0"},
                 {"LASS_WINO": "0", "LASS_FUSE_MASK": "0"}, {"LASS_WINO32": "0"}, {"LASS_WINO32": "0", "LASS_FUSE_MASK": "0"},
-                {"LASS_WINO32": "0", "LASS_FUSE_PRECONV": "0"}):
+                {"LASS_WINO32": "0", "LASS_FUSE_PRECONV": "0"}, {"LASS_WINO4": "0"}, {"LASS_WINO4": "0", "LASS_WINO32": "0"},
+                {"LASS_WINO4": "64"}, {"LASS_WINO4": "0", "LASS_FUSE_MASK": "0"}):
         got = run(env)
         assert float((got - ref).pow(2).mean().sqrt()) < 2e-5 * scale, env
 

@@ -184,5 +184,7 @@ def test_bench_single_rank_runs_the_rccl_exchange():
     assert ex.get("error") is None and ex["rccl_ranks"] == 1 and ex["rows"] == 2 and np.isfinite(ex["mean_sdr"])
     rf = res["roofline"]
     assert 0 < rf["frac"] <= 1.0 and rf["algorithmic_tflops"] >= rf["achieved"]
-    assert rf["winograd_mult_reduction"] == pytest.approx(2.25)
+    # 9 / 4 with F(2x2,3x3) everywhere; the layers lass_amd.arch.wino4_routed names run as F(4x4,3x3) (4 x fewer multiplies than direct)
+    assert 2.25 < rf["winograd_mult_reduction"] < 4.0 and "decoder_block6.conv1" in rf["winograd_f4x4_layers"]
+    assert "eager_ms_per_step" in res["launch"] and res["launch"]["eager_ms_per_step"] > 0
     assert set(res["modes"]) == {"bf16"} and 0 < res["modes"]["bf16"]["frac"] <= 1.0
