@@ -137,31 +137,6 @@ struct Phase16 {
             }
         }
     }
-    // Deep-pipeline forms (the 16- / 8-bin layers, NST > 2 stages in flight): EVERY wave issues exactly NPC image and NWPC
-    // weight operations per chunk, so that a counted `s_waitcnt vmcnt` can leave whole chunks outstanding.  A slot without a
-    // piece of its own (piece >= NPIECE, or a chunk behind the last one: real == false) becomes a zero-fill DMA (out-of-range
-    // source) into a 1-KiB dummy region: no memory traffic, the same operation count.
-    __device__ __forceinline__ void issue_dma_u(v4i32 rs, unsigned soff, unsigned img, unsigned dummy, int wave, bool real) {
-#pragma unroll
-        for (int i = 0; i < NPC; ++i) {
-            const int piece = wave + 4 * i;
-            if (real && piece < NPIECE) {  // (a real piece always has active lanes: its instruction is issued)
-                if (dvo[i] != 0xFFFFFFFFu) lds_dma_16B(rs, dvo[i], soff, img + (unsigned)piece * 1024u);
-            } else {
-                lds_dma_16B(rs, 0xC0000000u, 0u, dummy);
-            }
-        }
-    }
-    __device__ __forceinline__ void issue_wdma_u(v4i32 w_rs, unsigned wb, int Cout, unsigned wl_addr, unsigned dummy, int wave, bool real) {
-#pragma unroll
-        for (int i = 0; i < NWPC; ++i) {
-            const int piece = wave + 4 * i;
-            if (real && piece < NWPIECE)
-                lds_dma_16B(w_rs, wvo, wb + (unsigned)(piece * RPP * Cout) * 16u, wl_addr + (unsigned)piece * 1024u);
-            else
-                lds_dma_16B(w_rs, 0xC0000000u, 0u, dummy);
-        }
-    }
     // Buffer-addressed loads (descriptor + scalar byte offset + constant 32-bit lane offset: no VALU address arithmetic).
     // in_rs: this clip's input planes, c0b = byte offset of the chunk's first channel; w_rs / wl_rs: the weight matrix
     // (hi / lo) from column n0 on, wb = byte offset of the chunk's slab [tap][octet][Cout].
@@ -314,12 +289,9 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
     using PA = Phase16<TAPS, NCO, NPX, PW, PRO, SPLIT, PRE, INBF>;
     constexpr bool IN2BF = (FLAGS & F_IN2BF16) != 0;  // phase B reads the blocked bf16 raw copy by LDS-DMA
     using PB = Phase16<1, NCO, NPX, PW, false, SPLIT, false, IN2BF>;
-    // DMA-fed phases: image double-buffered; the weight slab too when it is DMA'd (bf16), else one register-staged region.
-    // The 16- / 8-bin layers (few, short workgroups: a chunk is 9 or fewer MFMAs per wave and the launch is one long chain of
-    // DMA round trips) keep NST = 4 chunks in flight instead of 2 (+ a 1-KiB dummy region for the uniform operation count).
-    constexpr int NST = (PW < 32 && SPLIT == 1) ? 4 : 2;
-    constexpr int PA_LDS = INBF ? (PA::WDMA ? NST * (PA::IN_U4 + PA::W_U4) + (NST > 2 ? 64 : 0) : 2 * PA::IN_U4 + PA::W_U4) : PA::LDS_U4;
-    constexpr int PB_LDS = IN2BF ? (PB::WDMA ? NST * (PB::IN_U4 + PB::W_U4) + (NST > 2 ? 64 : 0) : 2 * PB::IN_U4 + PB::W_U4) : PB::LDS_U4;
+    // DMA-fed phases: image double-buffered; the weight slab too when it is DMA'd (bf16), else one register-staged region
+    constexpr int PA_LDS = INBF ? 2 * PA::IN_U4 + (PA::WDMA ? 2 : 1) * PA::W_U4 : PA::LDS_U4;
+    constexpr int PB_LDS = IN2BF ? 2 * PB::IN_U4 + (PB::WDMA ? 2 : 1) * PB::W_U4 : PB::LDS_U4;
     constexpr int LDS_U4 = HASB ? MaxU<PA_LDS, PB_LDS>::v : PA_LDS;
     constexpr int PH = PA::PH, WROWS = PA::WROWS, PHT = PA::PHT, NT = PA::NT;
     constexpr bool MASK = (FLAGS & F_MASK) != 0;
@@ -430,32 +402,9 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
         const v4i32 wd_rs = make_rsrc_words(wa, wbytes);
         const v4i32 wdl_rs = SPLIT == 2 ? make_rsrc_words(wa_lo, wbytes) : wd_rs;
         const unsigned img0 = (unsigned)(size_t)(__attribute__((address_space(3))) uint4*)lds4;
-        const unsigned wl0 = img0 + (unsigned)(NST * PA::IN_U4 * 16);
+        const unsigned wl0 = img0 + (unsigned)(2 * PA::IN_U4 * 16);
         pa.init_dma(lane, wave, y0, x0, p.H, p.W);
         pa.init_wdma(lane, p.Nw);
-        if constexpr (NST > 2) {
-            // NST stages: chunk c lives in stage c % NST; NST - 1 chunks are requested ahead, the wait leaves NST - 2 of them
-            // in flight (every chunk = OPC operations of this wave, dummies included)
-            constexpr int OPC = PA::NPC + PA::NWPC;
-            const unsigned dummy = wl0 + (unsigned)(NST * PA::W_U4 * 16);
-            auto issueA = [&](int chn) {
-                const bool real = chn < nA;
-                const int stg = chn % NST;
-                pa.issue_dma_u(a_rs, real ? (unsigned)(chn * 2 * HW) * 16u : 0u, img0 + (unsigned)(stg * PA::IN_U4 * 16), dummy, wave, real);
-                pa.issue_wdma_u(wd_rs, real ? (unsigned)(chn * TAPS * 2 * p.Nw) * 16u : 0u, p.Nw, wl0 + (unsigned)(stg * PA::W_U4 * 16), dummy, wave, real);
-            };
-#pragma unroll
-            for (int c0 = 0; c0 < NST - 1; ++c0) issueA(c0);
-            __syncthreads();  // epilogue tables visible
-            init_acc();
-            for (int ch = 0; ch < nA; ++ch) {
-                wait_vmcnt<(NST - 2) * OPC>();  // this wave's pieces of chunk ch have landed
-                __syncthreads();                // ... everyone's have, and everyone has finished contracting chunk ch-1
-                issueA(ch + NST - 1);           // into the stage chunk ch-1 has just left
-                const int stg = ch % NST;
-                PA::compute(lds4 + stg * PA::IN_U4, lds4 + NST * PA::IN_U4 + stg * PA::W_U4, acc, lane, wave);
-            }
-        } else {
         pa.issue_dma(a_rs, al_rs, 0u, img0, wave);
         pa.issue_wdma(wd_rs, wdl_rs, 0u, p.Nw, wl0, wave);
         __syncthreads();  // epilogue tables visible
@@ -473,7 +422,6 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
                               wl0 + (unsigned)((cur ^ 1) * PA::W_U4 * 16), wave);
             }
             if (!(EXPF & 8)) PA::compute(lds4 + cur * PA::IN_U4, lds4 + 2 * PA::IN_U4 + cur * PA::W_U4, acc, lane, wave);
-        }
         }
         } else {
             // split operands: image of chunk ch+1 by LDS-DMA into the other buffer while chunk ch is contracted; weights
@@ -557,30 +505,10 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
         const v4i32 wd_rs = make_rsrc_words(wb2, wbytes2);
         const v4i32 wdl_rs = SPLIT == 2 ? make_rsrc_words(wb2_lo, wbytes2) : wd_rs;
         const unsigned img0 = (unsigned)(size_t)(__attribute__((address_space(3))) uint4*)lds4;
-        const unsigned wl0 = img0 + (unsigned)(NST * PB::IN_U4 * 16);
+        const unsigned wl0 = img0 + (unsigned)(2 * PB::IN_U4 * 16);
         pb.init_dma(lane, wave, y0, x0, p.H, p.W);
         pb.init_wdma(lane, p.Nw);
-        if constexpr (NST > 2) wait_vmcnt<0>();  // the main phase's trailing dummy operations are out of the way
         __syncthreads();  // phase A has finished with the LDS
-        if constexpr (NST > 2) {
-            constexpr int OPCB = PB::NPC + PB::NWPC;
-            const unsigned dummy = wl0 + (unsigned)(NST * PB::W_U4 * 16);
-            auto issueB = [&](int chn) {
-                const bool real = chn < nB;
-                const int stg = chn % NST;
-                pb.issue_dma_u(r_rs, real ? (unsigned)(chn * 2 * HW) * 16u : 0u, img0 + (unsigned)(stg * PB::IN_U4 * 16), dummy, wave, real);
-                pb.issue_wdma_u(wd_rs, real ? (unsigned)(chn * 2 * p.Nw) * 16u : 0u, p.Nw, wl0 + (unsigned)(stg * PB::W_U4 * 16), dummy, wave, real);
-            };
-#pragma unroll
-            for (int c0 = 0; c0 < NST - 1; ++c0) issueB(c0);
-            for (int ch = 0; ch < nB; ++ch) {
-                wait_vmcnt<(NST - 2) * OPCB>();
-                __syncthreads();
-                issueB(ch + NST - 1);
-                const int stg = ch % NST;
-                PB::compute(lds4 + stg * PB::IN_U4, lds4 + NST * PB::IN_U4 + stg * PB::W_U4, acc, lane, wave);
-            }
-        } else {
         pb.issue_dma(r_rs, r_rs, 0u, img0, wave);
         pb.issue_wdma(wd_rs, wdl_rs, 0u, p.Nw, wl0, wave);
         for (int ch = 0; ch < nB; ++ch) {
@@ -593,7 +521,6 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
                               wl0 + (unsigned)((cur ^ 1) * PB::W_U4 * 16), wave);
             }
             PB::compute(lds4 + cur * PB::IN_U4, lds4 + 2 * PB::IN_U4 + cur * PB::W_U4, acc, lane, wave);
-        }
         }
         } else {
             uint4* wl_b = lds4 + 2 * PB::IN_U4;
@@ -638,7 +565,6 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
 #ifdef LASS_CONV_DIAG
     dg_t3 = clock64();
 #endif
-    if constexpr (NST > 2) wait_vmcnt<0>();  // trailing dummy DMAs must land before this workgroup's LDS can be handed on
     if (FLAGS & F_TCONV)
         tconv_store<NCO, NPX, PW>(p, acc, b, n0, y0, x0, lane, wave, lds_tact);
     else

@@ -13,7 +13,7 @@ import sys
 sys.path.insert(0, '.')
 from lass_amd import arch
 
-CONV = re.compile(r'wino32_kernel|wino_kernel|conv_kernel|conv_bf16_kernel|fused_bf16_kernel')
+CONV = re.compile(r'wino4_kernel|wino32_kernel|wino_kernel|conv_kernel|conv_bf16_kernel|fused_bf16_kernel')
 
 
 def load(path):
@@ -37,11 +37,15 @@ def launch_sequence(convs):
     blocks = [e.name for e in arch.ENCODERS] + [d.name for d in arch.DECODERS]
     seq, it = [], iter(convs)
     for blk in blocks:
-        if blk + '.up' in by:
-            seq.append((blk + '.up', by[blk + '.up']['macs'], 0, 'tconv', by[blk + '.up']['h'], next(it)))
+        v = next(it)
         c1, c2 = by[blk + '.conv1'], by[blk + '.conv2']
         sc = by[blk + '.shortcut']['macs'] if blk + '.shortcut' in by else 0
-        v = next(it)
+        if blk + '.up' in by:
+            if 'dec6u_fused' in v['name']:  # bf16, round 4: the transposed conv runs inside the fused decoder kernel
+                seq.append((blk + ' (up + conv1 + conv2, one kernel)', c1['macs'] + c2['macs'] + by[blk + '.up']['macs'], sc, '3x3', c1['h'], v))
+                continue
+            seq.append((blk + '.up', by[blk + '.up']['macs'], 0, 'tconv', by[blk + '.up']['h'], v))
+            v = next(it)
         if 'fused' in v['name']:
             seq.append((blk + ' (conv1+conv2, one kernel)', c1['macs'] + c2['macs'], sc, '3x3', c1['h'], v))
         else:
@@ -65,7 +69,8 @@ if __name__ == '__main__':
         dt = (v['t1'] - v['t0']) / 1e9
         alg = 2.0 * B * (macs + sc)
         wino = mode == 'f32' and kind == '3x3' and h % 2 == 0 and 'wino' in v['name']
-        exe = 2.0 * B * (macs * (4.0 / 9.0 if wino else 1.0) + sc) * (3.0 if mode == 'bf16x3' else 1.0)
+        wfac = 0.25 if (wino and 'wino4_kernel' in v['name']) else (4.0 / 9.0 if wino else 1.0)  # F(4x4,3x3) / F(2x2,3x3) / direct
+        exe = 2.0 * B * (macs * wfac + sc) * (3.0 if mode == 'bf16x3' else 1.0)
         gui = v.get('GRBM_GUI_ACTIVE', 0.0) / 8.0
         busy = v.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / (gui * 1024.0) if gui else float('nan')
         clk = gui / dt / 1e9 if dt > 0 else float('nan')

@@ -28,7 +28,7 @@ def per_dispatch(path, counter):
 
 
 def is_conv3x3(name):
-    if 'wino_kernel' in name or 'wino32_kernel' in name or 'fused_bf16_kernel' in name:
+    if 'wino_kernel' in name or 'wino32_kernel' in name or 'wino4_kernel' in name or 'fused_bf16_kernel' in name:
         return True
     if 'conv_bf16_kernel<9' in name or 'conv_bf16_kernelILi9E' in name:
         return True
