@@ -415,7 +415,7 @@ int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int
                  float* a2, float* out, long out_bs, hipStream_t st, float* pool_out = nullptr, int pool_h = 2,
                  const PreConv* pre = nullptr, const MaskHead* mh = nullptr, const CatCopies* skip_out = nullptr,
                  const CatCopies* cat_in = nullptr, const Site* act_out = nullptr, const CatCopies* pool_copies = nullptr,
-                 long pool_bs = 0, const UpFuse* up = nullptr) {
+                 long pool_bs = 0, const UpFuse* up = nullptr, int cofs = 0) {  // cofs: this branch's channel offset inside the concatenated skip / pool
     const float* x0 = pre ? pre->x0 : nullptr;
     const Site& s1 = c->sites[rb.s1];
     const Site& s2 = c->sites[rb.s2];
@@ -475,7 +475,8 @@ int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int
             return fail(c, LASS_ERR_STATE, "blocked bf16 pooled copies need the bf16 kernels and the fused 2x2 pool");
         q.pool_out = nullptr;
         q.pool_bf16 = pool_copies->raw; q.pool_bf16_act = pool_copies->act;
-        q.pool_act_scale = pool_copies->scale; q.pool_act_shift = pool_copies->shift; q.act_shift_bs = c->n_shift;
+        q.pool_oct0 = cofs / 8; q.pool_noct = pool_copies->noct;
+        q.pool_act_scale = pool_copies->scale + cofs; q.pool_act_shift = pool_copies->shift + cofs; q.act_shift_bs = c->n_shift;
     }
     if (act_out) {  // bf16 mode: the block output goes to the next transposed conv only - written as ONE blocked bf16
                     // tensor with that conv's BN+FiLM+leaky prologue already applied (in `out`'s storage)
@@ -486,8 +487,8 @@ int run_resblock(lass_ctx* c, const ResBlock& rb, const float* x, long x_bs, int
     if (skip_out) {  // the skip goes out as the two blocked copies (concat channels [C, 2C)) instead of f32
         q.out = nullptr;
         q.out_bf16 = skip_out->raw; q.out_bf16_act = skip_out->act;
-        q.out_oct0 = rb.cout / 8; q.out_noct = skip_out->noct;
-        q.act_scale = skip_out->scale + rb.cout; q.act_shift = skip_out->shift + rb.cout; q.act_shift_bs = c->n_shift;
+        q.out_oct0 = (rb.cout + cofs) / 8; q.out_noct = skip_out->noct;
+        q.act_scale = skip_out->scale + rb.cout + cofs; q.act_shift = skip_out->shift + rb.cout + cofs; q.act_shift_bs = c->n_shift;
     }
     const bool wino2 = !bf2 && c->wino && rb.u2 && lass_wino_supported(q);
     if (rb.cin == rb.cout) {
@@ -1280,7 +1281,7 @@ static int separate_impl(lass_ctx* c, const float* mixture, const Components* co
     }
     // pre_conv (resunet.py:555) is normally never materialised: encoder_block1 forms it from x0 while staging
     const bool fuse_pre = c->fuse_preconv || nbr > 1;
-    // bf16 mode (ResUNet30 only): decoders 2-6 (2x2 up-sampling) take their concat as blocked bf16 copies written by the
+    // bf16 mode: decoders 2-6 (2x2 up-sampling) take their concat as blocked bf16 copies written by the
     // producers
     CatCopies cb[6];
     bool use_cb[6] = {false, false, false, false, false, false};
@@ -1289,7 +1290,7 @@ static int separate_impl(lass_ctx* c, const float* mixture, const Components* co
         const ResBlock& rd = c->dec[d];
         const ResBlock& re = c->enc[nbr - 1 + e];
         const long hw = (long)pl.eh[e] * pl.ew[e];
-        use_cb[d] = g.variant == 0 && c->fuse_catb && c->compute_mode == LASS_COMPUTE_BF16 && c->D[d].uh == 2 && c->D[d].uw == 2 &&
+        use_cb[d] = c->fuse_catb && c->compute_mode == LASS_COMPUTE_BF16 && c->D[d].uh == 2 && c->D[d].uw == 2 &&
                     c->fuse_pool && (pl.eh[e] % c->E[e].dh) == 0 && rd.cout % 16 == 0 && rd.b1 && rd.b2 && rd.bsc16 &&
                     c->up16[d] && re.b1 && re.b2 && (e != 0 || fuse_pre);
         cb[d].act = F(pl.cat[d]);
@@ -1304,7 +1305,7 @@ static int separate_impl(lass_ctx* c, const float* mixture, const Components* co
     for (int i = 0; i < 4; ++i) {
         const ResBlock& nx = c->enc[nbr - 1 + i + 1];
         const long hwo = (long)pl.eh[i + 1] * pl.ew[i + 1];
-        use_pc[i] = g.variant == 0 && c->fuse_catb && c->compute_mode == LASS_COMPUTE_BF16 && c->fuse_pool && c->E[i].dh == 2 &&
+        use_pc[i] = c->fuse_catb && c->compute_mode == LASS_COMPUTE_BF16 && c->fuse_pool && c->E[i].dh == 2 &&
                     (pl.eh[i] % 2) == 0 && pl.ew[i] % 32 == 0 && (i != 0 || fuse_pre) && use_cb[5 - i] && use_cb[5 - (i + 1)] &&
                     nx.cin != nx.cout && nx.cin % 16 == 0 && nx.b1 && nx.b2 && nx.bsc16;
         pc[i].act = F(pl.pool[i]);
@@ -1353,7 +1354,7 @@ static int separate_impl(lass_ctx* c, const float* mixture, const Components* co
             r = run_resblock(c, rb, xin, rb.cin * HW, B, H, W, shift, F(pl.a2), o, o_bs, st, fuse_pool ? pool_k : nullptr,
                              e.dh, pre.x0 ? &pre : nullptr, nullptr, (i < 5 && use_cb[5 - i]) ? &cb[5 - i] : nullptr,
                              (i >= 1 && i <= 4 && use_pc[i - 1]) ? &pc[i - 1] : nullptr, nullptr,
-                             (i < 4 && use_pc[i]) ? &pc[i] : nullptr, pool_bs);
+                             (i < 4 && use_pc[i]) ? &pc[i] : nullptr, pool_bs, nullptr, cofs);
             if (r) return r;
             if (i < 6 && !fuse_pool) {
                 ProfScope ps(c, st, P_POOL);
@@ -1383,7 +1384,7 @@ static int separate_impl(lass_ctx* c, const float* mixture, const Components* co
             if (r) return r;
         }
         // this decoder's output feeds only the next transposed conv: hand it over activated, as blocked bf16
-        const bool act_next = g.variant == 0 && d < 5 && c->fuse_catb && c->compute_mode == LASS_COMPUTE_BF16 && rb.b1 && rb.b2 &&
+        const bool act_next = d < 5 && c->fuse_catb && c->compute_mode == LASS_COMPUTE_BF16 && rb.b1 && rb.b2 &&
                               rb.bsc16 && rb.cout % 16 == 0 && c->up16[d + 1];
         x_act = act_next;
         // decoder_block6 (32 channels at the full resolution): after_conv + mask run in conv2's epilogue

@@ -236,7 +236,7 @@ __device__ __forceinline__ void store_tile(const ConvArgs& p, f32x16 (&acc)[NCO]
                     }
                     if (p.pool_bf16) {  // blocked bf16 copies for the next encoder block (raw + its conv1 prologue applied)
                         typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-                        const size_t clipo = (size_t)b * (p.N / 8) * Ho * Wo;
+                        const size_t clipo = (size_t)b * (p.pool_noct ? p.pool_noct : p.N / 8) * Ho * Wo;
 #pragma unroll
                         for (int g = 0; g < 4; g += 2) {  // octet pairs: whole 16-byte units per lane (pair_units)
                             uint2 raw2[2], act2[2];
@@ -251,7 +251,7 @@ __device__ __forceinline__ void store_tile(const ConvArgs& p, f32x16 (&acc)[NCO]
                                 raw2[h] = __builtin_bit_cast(uint2, raw);
                                 act2[h] = __builtin_bit_cast(uint2, act);
                             }
-                            const size_t unit = clipo + (size_t)((n0 + co * 32) / 8 + g + khalf) * Ho * Wo + (size_t)(y >> 1) * Wo + (x >> 1);
+                            const size_t unit = clipo + (size_t)(p.pool_oct0 + (n0 + co * 32) / 8 + g + khalf) * Ho * Wo + (size_t)(y >> 1) * Wo + (x >> 1);
                             const uint4 ur = pair_units(raw2[0], raw2[1]), ua = pair_units(act2[0], act2[1]);
                             if (!(lane & 1) && y + 1 < p.H) {
                                 *reinterpret_cast<uint4*>(reinterpret_cast<char*>(p.pool_bf16) + unit * 16) = ur;

@@ -66,6 +66,8 @@ struct ConvArgs {
     // conv1 prologue) instead of f32; replaces pool_out when set
     void* pool_bf16 = nullptr;
     void* pool_bf16_act = nullptr;
+    int pool_oct0 = 0;                      // the launch writes octets [pool_oct0, pool_oct0 + N/8) of pool_noct per clip
+    int pool_noct = 0;                      // (0: N / 8) - a channel slice of a wider pooled tensor (multi-STFT branches)
     const float* pool_act_scale = nullptr;  // indexed by this launch's output channel
     const float* pool_act_shift = nullptr;  // [B][act_shift_bs]
     const float* pre_w = nullptr;  // pre_conv (1x1, 1 -> 32) weight / bias for the *_PRE kinds

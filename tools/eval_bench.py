@@ -19,7 +19,7 @@ pl = AudioSep(ss_model=m.to("cuda:0").eval(), query_encoder=PrecomputedQueryEnco
 res = {}
 cases = [("device_mixing", {}), ("host_mixing", {"device_mixing": False, "io_workers": 1})]
 if os.environ.get("EVAL_BENCH_SWEEP"):  # decode-thread sweep
-    cases = [(f"device_mixing_w{w}", {"io_workers": w}) for w in (2, 4)] + [(f"host_mixing_w{w}", {"device_mixing": False, "io_workers": w}) for w in (1,)]
+    cases = [(f"device_mixing_w{w}", {"io_workers": w}) for w in (2, 4, 8)] + [(f"host_mixing_w{w}", {"device_mixing": False, "io_workers": w}) for w in (1,)]
 for name, kw in cases:
     ev = DCASEEvaluator(16000, csv_path, os.path.join(tmp, "lass_validation"), batch_size=16, **kw)
     ev(pl)  # warm-up (file cache, workspace)
