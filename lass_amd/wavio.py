@@ -4,9 +4,11 @@ Stands in for `librosa.load(path, sr=16000, mono=True)` (dcase_evaluator.py:73-7
 target rate: the load then reduces to PCM decode + mono down-mix + int->float scaling (x/32768 for int16, as
 soundfile/librosa do).  Whether the Zenodo validation audio is at 16 kHz is NOT established from the reference (its
 scripts/process_audio.sh converts TRAINING data with `sox -r 16000 -c 1`; the validation set's rate is not stated):
-`librosa.load` would resample such files (soxr/`kaiser_best`; librosa is absent here, so any resampler written in its
-place would be parity-unpinned) - this reader raises on a rate mismatch instead of guessing, and the caller resamples
-offline (e.g. the same `sox -r 16000 -c 1`).
+`librosa.load` would resample such files (librosa 0.10: `res_type="soxr_hq"`).  librosa / soxr are absent here, so a file at
+another rate is resampled by `scipy.signal.resample_poly` (polyphase FIR, Kaiser window) with a one-time warning: the
+result is band-limited correctly but is NOT bit-comparable with librosa's - **parity unpinned** at this boundary (SURVEY
+8c; the reference holds no fixture for it).  `read_wav(..., strict_rate=True)` (or LASS_WAV_STRICT_RATE=1) raises instead,
+for callers that would rather resample offline (`sox -r 16000 -c 1`, as scripts/process_audio.sh does for training data).
 """
 from __future__ import annotations
 
@@ -15,7 +17,19 @@ import struct
 import numpy as np
 
 
-def read_wav(path: str, sr: int | None = None) -> tuple[np.ndarray, int]:
+_warned_resample = False
+
+
+def _resample(x: np.ndarray, rate: int, sr: int) -> np.ndarray:
+    """Polyphase resampling rate -> sr (parity unpinned against librosa.load's soxr_hq, see the module docstring)."""
+    from math import gcd
+
+    from scipy.signal import resample_poly
+    g = gcd(int(rate), int(sr))
+    return resample_poly(x.astype(np.float64), sr // g, rate // g).astype(np.float32)
+
+
+def read_wav(path: str, sr: int | None = None, strict_rate: bool | None = None) -> tuple[np.ndarray, int]:
     with open(path, "rb") as f:
         data = f.read()
     if data[:4] != b"RIFF" or data[8:12] != b"WAVE":
@@ -45,7 +59,18 @@ def read_wav(path: str, sr: int | None = None) -> tuple[np.ndarray, int]:
     if ch > 1:
         x = x.reshape(-1, ch).mean(axis=1).astype(np.float32)  # librosa mono=True
     if sr is not None and rate != sr:
-        raise ValueError(f"{path}: sample rate {rate} != {sr}; resample offline (scripts/process_audio.sh)")
+        import os
+        if strict_rate is None:
+            strict_rate = os.environ.get("LASS_WAV_STRICT_RATE", "0") not in ("", "0")
+        if strict_rate:
+            raise ValueError(f"{path}: sample rate {rate} != {sr}; resample offline (e.g. sox -r {sr} -c 1)")
+        global _warned_resample
+        if not _warned_resample:
+            _warned_resample = True
+            import warnings
+            warnings.warn(f"{path}: {rate} Hz resampled to {sr} Hz with scipy.signal.resample_poly - librosa.load would use "
+                          "soxr_hq; parity with the reference is unpinned for resampled files (further files: no message)")
+        x, rate = _resample(x, rate, sr), sr
     return np.ascontiguousarray(x), rate
 
 

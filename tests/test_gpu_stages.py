@@ -356,3 +356,30 @@ def test_wino4_encoder_block_with_fused_pool(synthetic_sd, oracle_sd, monkeypatc
                                  orr.film(oracle_sd, cond, f"{name}->conv_block1->beta2"))
         assert _relerr(y.cpu(), ref) < 2e-5, (name, _relerr(y.cpu(), ref))
         assert _relerr(pool.cpu(), F.avg_pool2d(ref, (2, 2))) < 2e-5, name
+
+
+def test_hip_path_vs_reference_fixture_g4(golden_dir):
+    """Fixture G4 (tools/gen_golden.py --only g4): the reference's own models/resunet.py output for a SECOND seeded weight set,
+    other conditions and clips, L = 48 000 (301 -> 320 frames: every level from 320 x 512 down to 10 x 16, F(4x4,3x3) at the
+    levels that tile).  The HIP path is held to it on the full waveform, on decoder_block1's output in full and on row /
+    column margins of five large taps and of the separated spectrum - every element counted, so an isolated wrong pixel (a
+    tile edge, a padding rule) cannot hide behind a strided sample (round 3's weak spot)."""
+    from lass_amd.resunet import ResUNet30
+    from test_oracle_golden import G4_SEED, G4_TAPS, check_against_g4
+    g = np.load(os.path.join(golden_dir, "g4_second_weights.npz"))
+    B, L = 2, 48000
+    m = ResUNet30(1, 1, 512)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synthetic.make_state_dict(seed=G4_SEED).items()})
+    m = m.to(DEV).eval()
+    _, mix = synthetic.make_mixtures(B, L, first=20)
+    cond = synthetic.make_condition(B, seed=G4_SEED)
+    out = m({"mixture": torch.from_numpy(mix)[:, None, :].to(DEV), "condition": torch.from_numpy(cond).to(DEV)})["waveform"]
+    torch.cuda.synchronize()
+    T = arch.frames_for(L)
+    taps = {}
+    for n in G4_TAPS + ("decoder_block1",):
+        t = m.engine.workspace_tensor(n, B, L).clone()
+        if n in ("out_real", "out_imag"):
+            t = t[:, :, :T]
+        taps[n] = t.cpu().numpy()
+    check_against_g4(g, out.cpu().numpy(), taps)

@@ -107,7 +107,16 @@ def test_wav_roundtrip(tmp_path):
     y, _ = read_wav(p, 16000)
     assert np.max(np.abs(y - x)) <= 0.5 / 32768 + 1e-7
     with pytest.raises(ValueError):
-        read_wav(p, 32000)
+        read_wav(p, 32000, strict_rate=True)
+    # dcase_evaluator.py:73-74 (librosa.load(sr=16000)) resamples; here: scipy polyphase, labelled parity-unpinned, warns once.
+    # A 1 kHz tone written at 48 kHz comes back at 16 kHz with its frequency and amplitude intact.
+    t = np.arange(48000) / 48000.0
+    write_wav_f32(p, (0.5 * np.sin(2 * np.pi * 1000.0 * t)).astype(np.float32), 48000)
+    with pytest.warns(UserWarning, match="parity with the reference is unpinned"):
+        y, sr = read_wav(p, 16000)
+    assert sr == 16000 and y.shape == (16000,) and y.dtype == np.float32
+    ref = 0.5 * np.sin(2 * np.pi * 1000.0 * np.arange(16000) / 16000.0)
+    assert np.max(np.abs(y[200:-200] - ref[200:-200])) < 2e-3
 
 
 def test_stats_to_db_closed_form():

@@ -120,3 +120,50 @@ def test_g3_chunk_inference(golden_dir, synthetic_sd):
     # short input: the loop never runs and zeros come back (resunet.py:682)
     short = orr.chunk_inference(sd, {"mixture": torch.zeros(1, 1, 160000), "condition": torch.from_numpy(cond)})
     assert short.shape == (1, 160000) and not short.any()
+
+
+# ---- G4 (round 4): a second seeded weight set / condition / clips / length, every element of the taps counted ------------
+G4_SEED = synthetic.SEED + 17
+G4_TAPS = ("encoder_block1", "encoder_block3", "decoder_block3", "decoder_block5", "decoder_block6.up", "out_real", "out_imag")
+
+
+def _margins(t):
+    d = t.detach().double()
+    return d.sum(3).numpy(), d.sum(2).numpy()
+
+
+def check_against_g4(g, waveform, taps, tol_scale=1.0):
+    """Shared by the CPU (oracle) and GPU (HIP path) tests: waveform in full, decoder_block1 in full, row / column margins of
+    the larger taps (every element lands in one row sum and one column sum: an isolated wrong pixel cannot hide)."""
+    ref = g["waveform"]
+    err = float(np.sqrt(np.mean((waveform - ref) ** 2)))
+    assert err <= 3e-6 * tol_scale, err                      # north_star bar: 1e-4 RMS
+    assert float(np.max(np.abs(waveform - ref))) < 1e-4 * tol_scale
+    d1 = taps["decoder_block1"]
+    assert d1.shape == g["decoder_block1"].shape
+    scale = float(np.sqrt(np.mean(g["decoder_block1"] ** 2)))
+    assert float(np.max(np.abs(d1 - g["decoder_block1"]))) < 3e-4 * scale * tol_scale
+    for n in G4_TAPS:
+        t = taps[n]
+        rows, cols = _margins(torch.from_numpy(np.ascontiguousarray(t)))
+        rms = float(np.sqrt(g[n + "/stats"][2] / g[n + "/stats"][3]))
+        for got, want, cnt in ((rows, g[n + "/rows"], t.shape[3]), (cols, g[n + "/cols"], t.shape[2])):
+            assert got.shape == want.shape, n
+            # a sum of cnt elements of typical size rms: rounding noise ~ 1e-6 * rms * sqrt(cnt); bound 2e-4 * rms * sqrt(cnt)
+            assert float(np.max(np.abs(got - want))) < 2e-4 * rms * np.sqrt(cnt) * tol_scale, n
+
+
+def test_g4_second_weight_set(golden_dir):
+    """The oracle against the reference's own output for ANOTHER seeded weight set, conditions, clips and length (G4;
+    tools/gen_golden.py --only g4): the pin of the oracle does not rest on one set of weights."""
+    g = np.load(os.path.join(golden_dir, "g4_second_weights.npz"))
+    sd = orr.to_torch(synthetic.make_state_dict(seed=G4_SEED))
+    _, mix = synthetic.make_mixtures(2, 48000, first=20)
+    cond = synthetic.make_condition(2, seed=G4_SEED)
+    taps = {}
+    out = orr.forward(sd, {"mixture": torch.from_numpy(mix)[:, None], "condition": torch.from_numpy(cond)}, taps, stft_form="dft")
+    got = {}
+    for n in G4_TAPS + ("decoder_block1",):
+        v = taps[n]
+        got[n] = (v[1] if isinstance(v, tuple) else v).numpy()
+    check_against_g4(g, out["waveform"].numpy(), got)
