@@ -675,7 +675,7 @@ const ResBlock* find_block(const lass_ctx* c, const std::string& prefix) {
 
 extern "C" {
 
-int lass_version(void) { return 10100; }  // 1.1.0: multi-STFT model, fused iSTFT, graph replay
+int lass_version(void) { return 10200; }  // 1.2.0: F(4x4,3x3) kernels, lass_set_graph_replay (1.1.0: multi-STFT model, fused iSTFT, graph replay)
 
 const char* lass_last_error(const lass_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
