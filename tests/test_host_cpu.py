@@ -304,4 +304,8 @@ def test_committed_traffic_profiles_are_complete():
         assert d["dtype"] == dtype and d["launches"] >= 20
         assert d["traffic_bytes_per_launch"] == pytest.approx(d["fetch_bytes_per_launch"] + d["write_bytes_per_launch"], rel=1e-9)
         assert re.fullmatch(r"[0-9a-f]{64}", d["source_hash"])
-        assert 1.0 <= d["traffic_bytes_per_launch"] / {"f32": 862090791.4, "bf16": 431045395.7}[dtype] < 3.0
+        # against the per-LAUNCH-fusion ideal (lass_amd.arch.conv3x3_bytes_per_clip: every launch reads its inputs and writes its
+        # outputs once, 26 launches): f32 sits above it (halo re-reads); bf16 may sit BELOW it since rounds 3 / 4 - two blocks run as
+        # one kernel each (their 32-channel intermediates stay in LDS) and decoder_block6's up-sampled input is never stored
+        lo = {"f32": 1.0, "bf16": 0.8}[dtype]
+        assert lo <= d["traffic_bytes_per_launch"] / {"f32": 862090791.4, "bf16": 431045395.7}[dtype] < 3.0
