@@ -219,6 +219,17 @@ def test_graph_replay_equals_eager(synthetic_sd, monkeypatch):
     for _ in range(3):
         y = eng.separate(torch.from_numpy(mix[:B]).to(DEV).clone(), cond)
     assert torch.equal(y, outs[0]) and eng.graph_stats()[1] <= caps_before + 1
+    # lass_set_graph_replay (round 4, bench.py's eager leg): off -> the same call launches eagerly (no replay counted), same
+    # bits; on again -> the cached graph is replayed without a new capture.  An argument error while a capture would be due
+    # is reported as such and leaves replay enabled (round-3 advice).
+    caps0, reps0 = eng.graph_stats()[1:]
+    eng.set_graph_replay(False)
+    assert eng.graph_stats()[0] is False
+    eng.separate(x, cond, out)
+    assert eng.graph_stats()[1:] == (caps0, reps0) and torch.equal(out, replay_new)
+    eng.set_graph_replay(True)
+    eng.separate(x, cond, out)
+    assert eng.graph_stats() == (True, caps0, reps0 + 1) and torch.equal(out, replay_new)
 
 
 def test_workspace_reuse_and_graphs_across_ragged_batches(synthetic_sd):
@@ -383,3 +394,11 @@ def test_hip_path_vs_reference_fixture_g4(golden_dir):
             t = t[:, :, :T]
         taps[n] = t.cpu().numpy()
     check_against_g4(g, out.cpu().numpy(), taps)
+    # the bf16 modes against the same reference output: split operands inside the f32 tolerance class, plain bf16 within 5 %
+    ref = torch.from_numpy(g["waveform"])
+    inp = {"mixture": torch.from_numpy(mix)[:, None, :].to(DEV), "condition": torch.from_numpy(cond).to(DEV)}
+    for mode, bound in (("bf16x3", 1e-5), ("bf16", 5e-2 * float(ref.pow(2).mean().sqrt()))):
+        w = m.set_compute_dtype(mode)(inp)["waveform"].cpu()
+        err = float((w - ref).pow(2).mean().sqrt())
+        print("G4", mode, "waveform RMS error vs the reference's own output", err)
+        assert err <= bound, (mode, err)
