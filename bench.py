@@ -72,6 +72,13 @@ def launch_command(argv, nproc: int, port: int):
             "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py")] + list(argv)
 
 
+def half_batch_overlap(mode: str, B: int) -> bool:
+    """Whether lass_separate runs this batch as two overlapping half-batches (api.hip split_halves; include/lass_hip.h)."""
+    env = os.environ.get("LASS_SPLIT")
+    on = (env != "0") if env is not None else mode == "bf16"
+    return bool(on and B >= 8 and B % 2 == 0)
+
+
 def parent_launch(args, argv) -> int:
     """Spawn the ranks as fresh children (a GPU-initialised process must never exec or fork into ranks)."""
     cmd = launch_command(argv, args.gpus, free_port())
@@ -402,7 +409,7 @@ def main():
         assert not check or torch.isfinite(out).all()
         c1, r1 = e2.graph_stats()[1:]
         modes[m] = mode_record(m, dt_m, args.steps, profiled(e2, psteps))
-        modes[m]["launch"] = {"captures": c1 - c0, "replays": r1 - r0}
+        modes[m]["launch"] = {"captures": c1 - c0, "replays": r1 - r0, "half_batch_overlap": half_batch_overlap(m, B)}
         alg_b = float(B) * arch.conv3x3_bytes_per_clip(L, 2 if m == "bf16" else 4) / max(1.0, modes[m]["launches_per_step"])
         modes[m]["algorithmic_bytes_per_launch"] = alg_b
         modes[m].update(traffic_fields(m, alg_b, (B, L) == (16, 160000)))
@@ -509,13 +516,16 @@ def main():
             "realtime_factor": world * B * args.steps / dt * (L / 16000.0),
             "exchange": exch,
             "launch": {"hipgraph_replay": graph_on, "captures": graph_caps, "replays_in_headline_loops": graph_replays,
+                       "half_batch_overlap": half_batch_overlap(args.dtype, B),
                        "extra_warmup_for_capture": extra_warm,
                        "eager_ms_per_step": dt_eager / args.steps * 1e3,
                        "profiled_ms_per_step": sum(v for v in head["kernel_ms_per_step"].values()),
                        "note": "ms_per_step / value: the timed loop replays ONE captured hipGraph of the ~40 launches per "
                                "step; eager_ms_per_step: the same loop with replay switched off; kernel_ms_per_step / "
                                "class_ms_per_step: a third, eager loop with HIP events around every kernel class (their sum = "
-                               "profiled_ms_per_step: events add the drain between classes)"},
+                               "profiled_ms_per_step: events add the drain between classes).  half_batch_overlap: the step "
+                               "runs as two half-batches on two streams (bf16 mode's default, LASS_SPLIT; DESIGN.md 5b) - "
+                               "never in the profiled loop, whose classes must not overlap"},
             "roofline": {"bound": "mfma", "kernel": kernel,
                          "achieved": head["executed_tflops"], "peak": head["peak_tflops"], "unit": "TFLOP/s",
                          "frac": head["frac"],

@@ -101,7 +101,13 @@ int lass_workspace_bytes(const lass_ctx* ctx, int B, int L, size_t* bytes);
 
 /* The hot path.  mixture (B,L) f32, condition (B,512) f32 -> out (B,L) f32.
  * Replaces: ResUNet30.forward(input_dict)["waveform"] (resunet.py:640-653) with mixture/out squeezed of their
- * singleton channel axis. */
+ * singleton channel axis.
+ * Scheduling: in LASS_COMPUTE_BF16 mode (LASS_SPLIT=1 / 0 forces it on / off in every mode) an even batch of >= 8 clips
+ * runs as two independent half-batches, the second on an internal stream forked from / joined to `stream` by events,
+ * so that one half's small launches and launch tails overlap the other half's full-size ones.  Clips are independent:
+ * the results are bit-identical to the unsplit run, and `stream` still orders the whole call.  lass_workspace_bytes
+ * already accounts for it; lass_workspace_tensor reports LASS_ERR_STATE for such a batch (its workspace holds two
+ * half-batch layouts). */
 int lass_separate(lass_ctx* ctx, const float* mixture, const float* condition, float* out, int B, int L,
                   void* workspace, size_t workspace_bytes, void* stream);
 
@@ -194,7 +200,8 @@ int lass_front_end(lass_ctx* ctx, const float* wav, int B, int L, float* mag, fl
  * "mag" "cos" "sin" "x0" "out_real" "out_imag", "encoder_blockN" (the skip, stored in place inside the decoder's concat
  * buffer), "encoder_blockN.pool", "conv_block7a", "decoder_blockN.up" (transposed-conv half of the concat),
  * "decoder_blockN" (N = 6 is consumed by the fused output head and never written).  For parity tests of the fused
- * stages against the reference's own taps.  Returns LASS_ERR_ARG for an unknown name. */
+ * stages against the reference's own taps.  Returns LASS_ERR_ARG for an unknown name, LASS_ERR_STATE for a batch that
+ * lass_separate runs as two half-batches (see there). */
 int lass_workspace_tensor(const lass_ctx* ctx, int B, int L, const char* name, size_t* offset, int64_t shape[4],
                           int64_t strides[4]);
 

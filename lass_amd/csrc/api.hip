@@ -5,6 +5,7 @@
 // second channel half of the decoder's concat buffer and the transposed conv writes the first half.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -141,6 +142,15 @@ struct lass_ctx {
     std::vector<hipGraphExec_t> g_retired;  // replaced execs: a replay may still be in flight on some stream, so they are
                                             // destroyed only behind a device synchronisation (lass_finalize / lass_destroy)
     hipStream_t g_stream = nullptr;
+    // Half-batch overlap: an even batch of >= 8 clips runs as two independent half-batches on two streams (clips are
+    // independent: eval-mode BN) - the second on `s2`, forked from / joined to the caller's stream by events - so that one
+    // half's small launches (the 16-/8-bin layers: a few hundred workgroups) and launch tails run beside the other half's
+    // full-size launches.  Same kernels, same per-clip arithmetic (bit-identical: batch invariance), same workspace size.
+    // -1: on in bf16 mode (measured +3.4 %), off in the f32 / split-bf16 modes (+0.5 / +1.1 %: within the run-to-run spread);
+    // LASS_SPLIT=1 / 0 forces it.  DESIGN.md section 5b has the measurements and the co-residency hazard found on the way.
+    int split_batch = -1;
+    hipStream_t s2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     unsigned long gen = 0;         // bumped by lass_finalize: a graph holds weight pointers
     long g_replays = 0, g_captures = 0;
     bool profiling = false;
@@ -665,6 +675,12 @@ void drop_graphs(lass_ctx* c) {
     c->g_retired.clear();
 }
 
+// A batch is split into two overlapping half-batches when it is large enough for each half to fill the GPU on its own
+bool split_halves(const lass_ctx* c, int B) {
+    const bool on = c->split_batch > 0 || (c->split_batch < 0 && c->compute_mode == LASS_COMPUTE_BF16);
+    return on && !c->profiling && B >= 8 && (B % 2) == 0;
+}
+
 const ResBlock* find_block(const lass_ctx* c, const std::string& prefix) {
     for (const auto& rb : c->enc) if (rb.prefix == prefix) return &rb;
     for (const auto& rb : c->dec) if (rb.prefix == prefix) return &rb;
@@ -714,6 +730,7 @@ static int create_impl(lass_ctx** out, int device_id, const Geometry& geom) {
     if (const char* e = getenv("LASS_FUSE_BLOCK")) c->fuse_block = atoi(e) != 0;
     if (const char* e = getenv("LASS_FUSE_UP")) c->fuse_up = atoi(e) != 0;
     if (const char* e = getenv("LASS_WINO4")) c->wino4_mincin = atoi(e);
+    if (const char* e = getenv("LASS_SPLIT")) c->split_batch = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("LASS_FUSE_PRECONV")) c->fuse_preconv = atoi(e) != 0;
     if (const char* e = getenv("LASS_GRAPH")) c->use_graph = atoi(e) != 0;
     c->prof.resize(P_COUNT);
@@ -784,6 +801,9 @@ int lass_destroy(lass_ctx* c) {
     (void)hipDeviceSynchronize();  // no replay of a graph below is in flight any more
     drop_graphs(c);
     if (c->g_stream) (void)hipStreamDestroy(c->g_stream);
+    if (c->s2) (void)hipStreamDestroy(c->s2);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     (void)hipFree(c->tw2k);
     delete c;
     return 0;
@@ -996,6 +1016,12 @@ int lass_workspace_bytes(const lass_ctx* c, int B, int L, size_t* bytes) {
     Plan pl;
     if (make_plan(c, B, L, &pl)) return LASS_ERR_ARG;  // B < 1, L <= 512 or L beyond the 32-bit per-clip addressing limit
     *bytes = pl.total;
+    if (split_halves(c, B)) {  // two half-batch plans side by side (they differ from the whole plan by alignment padding only)
+        Plan ph;
+        if (make_plan(c, B / 2, L, &ph)) return LASS_ERR_ARG;
+        const size_t two = 2 * ((ph.total + 255) / 256 * 256);
+        if (two > *bytes) *bytes = two;
+    }
     return 0;
 }
 
@@ -1147,6 +1173,8 @@ int lass_front_end(lass_ctx* c, const float* wav, int B, int L, float* mag, floa
 int lass_workspace_tensor(const lass_ctx* c, int B, int L, const char* name_c, size_t* offset, int64_t shape[4],
                           int64_t strides[4]) {
     if (!c || !name_c || !offset || !shape || !strides) return LASS_ERR_ARG;
+    // a batch that runs as two half-batches (B >= 8, LASS_SPLIT) keeps two half-batch layouts in its workspace, not this one
+    if (split_halves(c, B)) return LASS_ERR_STATE;
     Plan pl;
     if (make_plan(c, B, L, &pl)) return LASS_ERR_ARG;
     const Geometry& g = c->g;
@@ -1408,6 +1436,33 @@ static int separate_impl(lass_ctx* c, const float* mixture, const Components* co
     return 0;
 }
 
+// lass_separate's launches, whole or as two overlapping half-batches (lass_ctx::split_batch).  Capture-safe: under stream
+// capture the event pair makes `s2` a parallel branch of the same graph.
+static int separate_any(lass_ctx* c, const float* mixture, const float* condition, float* out, int B, int L, void* workspace,
+                        size_t workspace_bytes, hipStream_t stream) {
+    Plan ph;
+    if (!c->finalized || !mixture || !condition || !out || !workspace || !split_halves(c, B) || make_plan(c, B / 2, L, &ph) ||
+        2 * ((ph.total + 255) / 256 * 256) > workspace_bytes)
+        return separate_impl(c, mixture, nullptr, condition, out, B, L, workspace, workspace_bytes, stream, "lass_separate");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->s2) {
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->s2, hipStreamNonBlocking));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    }
+    const int h = B / 2;
+    const size_t half_ws = (ph.total + 255) / 256 * 256;
+    HIP_TRY(c, hipEventRecord(c->ev_fork, stream));
+    HIP_TRY(c, hipStreamWaitEvent(c->s2, c->ev_fork, 0));
+    const int r = separate_impl(c, mixture, nullptr, condition, out, h, L, workspace, half_ws, stream, "lass_separate");
+    const int r2 = separate_impl(c, mixture + (size_t)h * L, nullptr, condition + (size_t)h * LASS_COND, out + (size_t)h * L, h, L,
+                                 (char*)workspace + half_ws, half_ws, c->s2, "lass_separate");
+    // the join is recorded even after a failure: a capturing stream must get its branch back
+    HIP_TRY(c, hipEventRecord(c->ev_join, c->s2));
+    HIP_TRY(c, hipStreamWaitEvent(stream, c->ev_join, 0));
+    return r ? r : r2;
+}
+
 int lass_separate(lass_ctx* c, const float* mixture, const float* condition, float* out, int B, int L, void* workspace,
                   size_t workspace_bytes, void* stream) {
     if (!c) return LASS_ERR_ARG;
@@ -1459,15 +1514,19 @@ int lass_separate(lass_ctx* c, const float* mixture, const float* condition, flo
                 Plan pl0;
                 if (!condition || !out || !workspace || make_plan(c, B, L, &pl0) || workspace_bytes < pl0.total ||
                     ((uintptr_t)workspace & 255) != 0)
-                    return separate_impl(c, mixture, nullptr, condition, out, B, L, workspace, workspace_bytes, stream, "lass_separate");
+                    return separate_any(c, mixture, condition, out, B, L, workspace, workspace_bytes, (hipStream_t)stream);
                 slot->need = pl0.total;
+                if (split_halves(c, B)) {  // (checked again at capture time by separate_any: smaller workspaces run unsplit)
+                    Plan ph0;
+                    if (!make_plan(c, B / 2, L, &ph0) && 2 * ((ph0.total + 255) / 256 * 256) <= workspace_bytes)
+                        slot->need = std::max(slot->need, 2 * ((ph0.total + 255) / 256 * 256));
+                }
             }
             HIP_TRY(c, hipSetDevice(c->device));
             if (!c->g_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->g_stream, hipStreamNonBlocking));
             bool ok = false;
             if (hipStreamBeginCapture(c->g_stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-                const int r = separate_impl(c, mixture, nullptr, condition, out, B, L, workspace, workspace_bytes, c->g_stream,
-                                            "lass_separate");
+                const int r = separate_any(c, mixture, condition, out, B, L, workspace, workspace_bytes, c->g_stream);
                 hipGraph_t graph = nullptr;
                 const hipError_t e = hipStreamEndCapture(c->g_stream, &graph);  // always ends the capture, also after a failure
                 if (r == 0 && e == hipSuccess && graph && hipGraphInstantiate(&slot->exec, graph, nullptr, nullptr, 0) == hipSuccess)
@@ -1488,7 +1547,7 @@ int lass_separate(lass_ctx* c, const float* mixture, const float* condition, flo
             c->err.clear();
         }
     }
-    return separate_impl(c, mixture, nullptr, condition, out, B, L, workspace, workspace_bytes, stream, "lass_separate");
+    return separate_any(c, mixture, condition, out, B, L, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 int lass_set_graph_replay(lass_ctx* c, int enabled) {

@@ -631,3 +631,47 @@ def test_bf16_modes_full_size_metrics_vs_f32(synthetic_sd):
         assert d < 0.05, (mode, d)
     assert _rms(outs["bf16x3"] - outs["f32"]) <= 1e-5
     assert 1e-6 < _rms(outs["bf16"] - outs["f32"]) < 5e-2 * _rms(outs["f32"])   # really the bf16 kernels, and sane
+
+
+@pytest.mark.parametrize("mode", ["bf16", "f32", "bf16x3"])
+def test_half_batch_overlap_is_bit_identical(synthetic_sd, monkeypatch, mode):
+    """lass_separate's two overlapping half-batches (on by default in bf16 mode, LASS_SPLIT=1 elsewhere) against
+    the unsplit run on the same 16 clips: the same bits, call after call, launched eagerly and as a replayed graph."""
+    from lass_amd.resunet import ResUNet30
+    B, L = 16, 160000
+    _, mix = synthetic.make_mixtures(4, L)
+    mix = np.concatenate([mix * g for g in (1.0, 0.8, 0.6, 0.4)])[:B]
+    x = torch.from_numpy(mix).to(DEV)
+    cond = torch.from_numpy(synthetic.make_condition(B)).to(DEV)
+    engines = {}
+    for split in ("1", "0"):
+        monkeypatch.setenv("LASS_SPLIT", split)
+        m = ResUNet30(1, 1, 512)
+        m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synthetic_sd.items()})
+        engines[split] = m.to(DEV).eval().set_compute_dtype(mode).engine
+    monkeypatch.delenv("LASS_SPLIT")
+    assert engines["1"].workspace_bytes(B, L) >= engines["0"].workspace_bytes(B, L)
+    ref = engines["0"].separate(x, cond).clone()
+    assert torch.isfinite(ref).all() and float(ref.abs().max()) > 1e-3
+    for graph in (False, True):
+        engines["1"].set_graph_replay(graph)
+        for call in range(6):
+            out = engines["1"].separate(x, cond)
+            torch.cuda.synchronize()
+            assert torch.equal(out, ref), (mode, "graph" if graph else "eager", call)
+    _, captures, replays = engines["1"].graph_stats()
+    assert captures >= 1 and replays >= 1, (captures, replays)   # the two-stream form captures as one graph with two branches
+    with pytest.raises(Exception, match="half-batches"):   # the workspace holds two half-batch layouts, not the B = 16 one
+        engines["1"].workspace_tensor("out_real", B, L)
+
+
+def test_front_end_is_exact_beside_a_bf16_separation():
+    """Regression check for the co-residency hazard of DESIGN.md 5b: STFT front-end launches on one stream while lass_separate
+    (bf16) runs on another.  With packed-f32 instructions in stft.hip about one launch in six came out wrong; as built by
+    __graft_entry__.build() (-fno-slp-vectorize for the kernels without matrix instructions) every one is exact."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("coresident_stress", os.path.join(os.path.dirname(__file__), "..", "tools",
+                                                                                   "coresident_stress.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run("bf16", nrep=60, trials=2, verbose=False) == 0

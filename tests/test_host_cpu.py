@@ -259,6 +259,38 @@ def test_build_is_warning_free(tmp_path):
         assert "warning" not in r.stderr, r.stderr[-2000:]
 
 
+def test_kernels_without_mfma_carry_no_packed_f32(tmp_path):
+    """on gfx950 a wave executing packed-f32 arithmetic (v_pk_{add,mul,fma}_f32) returned wrong values while a
+    workgroup of a bf16 conv kernel (v_mfma_f32_32x32x16_bf16 fed from LDS) was resident on the same CU - seen on the STFT
+    beside lass_separate on another stream.  The kernels that may run beside the conv kernels of another stream (everything
+    without matrix instructions: stft.hip, misc.hip) are therefore built with -fno-slp-vectorize; this audits the ISA the build
+    flags of __graft_entry__.py produce, and that every other kernel file is an MFMA one."""
+    import shutil
+    import __graft_entry__ as ge
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc in this environment")
+    csrc = os.path.join(ROOT, "lass_amd", "csrc")
+    for name in ge.SOURCES:
+        text = open(os.path.join(csrc, name)).read()
+        if "__global__" in text and "mfma" not in text:
+            assert "-fno-slp-vectorize" in ge.EXTRA_FLAGS.get(name, []), name
+    procs = {}
+    for name, extra in ge.EXTRA_FLAGS.items():
+        out = os.path.join(tmp_path, name + ".s")
+        flags = [f for f in ge.FLAGS if f != "-fPIC"]
+        procs[name] = (out, subprocess.Popen([hipcc] + flags + extra + ["-S", "--cuda-device-only", os.path.join(csrc, name), "-o", out],
+                                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    for name, (out, pr) in procs.items():
+        _, err = pr.communicate(timeout=900)
+        assert pr.returncode == 0, err[-2000:]
+        isa = open(out).read()
+        packed = [ln.strip() for ln in isa.split("\n") if re.search(r"\bv_pk_[a-z0-9]+_f32\b", ln)]
+        assert not packed, (name, len(packed), packed[:3])
+        assert "v_mfma" not in isa, name
+        assert isa.count("s_endpgm") >= 3, name   # really the kernels
+
+
 # ---- bench.py: the PMC traffic number is only reported for the kernels it was measured at ----------------------------
 def _import_bench():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
