@@ -74,9 +74,7 @@ def launch_command(argv, nproc: int, port: int):
 
 def half_batch_overlap(mode: str, B: int) -> bool:
     """Whether lass_separate runs this batch as two overlapping half-batches (api.hip split_halves; include/lass_hip.h)."""
-    env = os.environ.get("LASS_SPLIT")
-    on = (env != "0") if env is not None else mode == "bf16"
-    return bool(on and B >= 8 and B % 2 == 0)
+    return bool(os.environ.get("LASS_SPLIT", "1") != "0" and B >= 8 and B % 2 == 0)
 
 
 def parent_launch(args, argv) -> int:
@@ -524,7 +522,7 @@ def main():
                                "step; eager_ms_per_step: the same loop with replay switched off; kernel_ms_per_step / "
                                "class_ms_per_step: a third, eager loop with HIP events around every kernel class (their sum = "
                                "profiled_ms_per_step: events add the drain between classes).  half_batch_overlap: the step "
-                               "runs as two half-batches on two streams (bf16 mode's default, LASS_SPLIT; DESIGN.md 5b) - "
+                               "runs as two half-batches on two streams (LASS_SPLIT; DESIGN.md 5b) - "
                                "never in the profiled loop, whose classes must not overlap"},
             "roofline": {"bound": "mfma", "kernel": kernel,
                          "achieved": head["executed_tflops"], "peak": head["peak_tflops"], "unit": "TFLOP/s",

@@ -146,9 +146,9 @@ struct lass_ctx {
     // independent: eval-mode BN) - the second on `s2`, forked from / joined to the caller's stream by events - so that one
     // half's small launches (the 16-/8-bin layers: a few hundred workgroups) and launch tails run beside the other half's
     // full-size launches.  Same kernels, same per-clip arithmetic (bit-identical: batch invariance), same workspace size.
-    // -1: on in bf16 mode (measured +3.4 %), off in the f32 / split-bf16 modes (+0.5 / +1.1 %: within the run-to-run spread);
-    // LASS_SPLIT=1 / 0 forces it.  DESIGN.md section 5b has the measurements and the co-residency hazard found on the way.
-    int split_batch = -1;
+    // Measured: bf16 +3.4 %, f32 +0.5 ... +2.1 % depending on the box, split-bf16 +1.1 %.  LASS_SPLIT=0 switches it off.
+    // DESIGN.md section 5b has the measurements and the co-residency hazard found on the way.
+    int split_batch = 1;
     hipStream_t s2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     unsigned long gen = 0;         // bumped by lass_finalize: a graph holds weight pointers
@@ -677,8 +677,7 @@ void drop_graphs(lass_ctx* c) {
 
 // A batch is split into two overlapping half-batches when it is large enough for each half to fill the GPU on its own
 bool split_halves(const lass_ctx* c, int B) {
-    const bool on = c->split_batch > 0 || (c->split_batch < 0 && c->compute_mode == LASS_COMPUTE_BF16);
-    return on && !c->profiling && B >= 8 && (B % 2) == 0;
+    return c->split_batch > 0 && !c->profiling && B >= 8 && (B % 2) == 0;
 }
 
 const ResBlock* find_block(const lass_ctx* c, const std::string& prefix) {

@@ -228,7 +228,7 @@ __device__ __forceinline__ void store_tile(const ConvArgs& p, f32x16 (&acc)[NCO]
                     float pooled[16];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const float o0 = __shfl_xor(val[2 * pp][r], 1, 64), o1 = __shfl_xor(val[2 * pp + 1][r], 1, 64);
+                        const float o0 = lane_xor1(val[2 * pp][r]), o1 = lane_xor1(val[2 * pp + 1][r]);
                         float sum = val[2 * pp][r] + o0;
                         sum += val[2 * pp + 1][r];
                         sum += o1;
@@ -272,7 +272,7 @@ __device__ __forceinline__ void store_tile(const ConvArgs& p, f32x16 (&acc)[NCO]
                                  (size_t)min(y, p.H - 1) * Wo + (x >> 1);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const float sum = val[px][r] + __shfl_xor(val[px][r], 1, 64);
+                        const float sum = val[px][r] + lane_xor1(val[px][r]);
                         if (!(lane & 1) && y < p.H) dst[(size_t)((r & 3) + 8 * (r >> 2)) * p.H * Wo] = sum * 0.5f;
                     }
                 }

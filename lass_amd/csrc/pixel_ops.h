@@ -8,6 +8,12 @@ namespace {
 
 __device__ __forceinline__ float leaky(float v) { return fmaxf(v, 0.01f * v); }  // == v > 0 ? v : 0.01 v
 
+// Value of lane ^ 1 (the horizontal neighbour in the 2x2 pooling windows): a DPP quad permutation [1,0,3,2] on the VALU instead
+// of __shfl_xor's ds_bpermute_b32 through the LDS pipe, which the MFMA operand reads of the co-resident workgroups saturate.
+__device__ __forceinline__ float lane_xor1(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));
+}
+
 
 // The complex ratio mask of one time-frequency bin from its three after_conv logits (resunet.py:476-507; torchlibrosa
 // magphase clamps |M| at 1e-10); bin 512 is the zero padding of resunet.py:573, whose output is exactly 0.

@@ -99,7 +99,7 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& p, f32x4 (&acc)[16
             {
                 const bool odd = (lane & 1) != 0;
                 const float sx = odd ? y[0][0] : y[1][0], sy = odd ? y[0][1] : y[1][1];  // the row the partner stores
-                const float rx = __shfl_xor(sx, 1, 64), ry = __shfl_xor(sy, 1, 64);
+                const float rx = lane_xor1(sx), ry = lane_xor1(sy);
                 float* dst = p.out + (size_t)b * p.out_bs + pix;
                 const float4 v = odd ? make_float4(rx, ry, y[1][0], y[1][1]) : make_float4(y[0][0], y[0][1], rx, ry);
                 if (oy < p.H) *reinterpret_cast<float4*>(odd ? dst + p.W - 2 : dst) = v;

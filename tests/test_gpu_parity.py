@@ -635,7 +635,7 @@ def test_bf16_modes_full_size_metrics_vs_f32(synthetic_sd):
 
 @pytest.mark.parametrize("mode", ["bf16", "f32", "bf16x3"])
 def test_half_batch_overlap_is_bit_identical(synthetic_sd, monkeypatch, mode):
-    """lass_separate's two overlapping half-batches (on by default in bf16 mode, LASS_SPLIT=1 elsewhere) against
+    """lass_separate's two overlapping half-batches (the default for an even batch of >= 8 clips) against
     the unsplit run on the same 16 clips: the same bits, call after call, launched eagerly and as a replayed graph."""
     from lass_amd.resunet import ResUNet30
     B, L = 16, 160000

@@ -1,7 +1,7 @@
 # Round profile set (run on the GPU box: `bash tools/profile_round.sh`); outputs under gpurun_out/prof_round/, the
 # summaries to commit are copied into profiles/<round>/ by hand afterwards.
-#  1. rocprofv3 --kernel-trace --stats of the default bench (f32 headline + bf16 / bf16x3 modes in one run; LASS_SPLIT=0: per-kernel
-#     durations are only attributable when the two half-batches of bf16 mode do not overlap)
+#  1. rocprofv3 --kernel-trace --stats of the default bench (f32 headline + bf16 / bf16x3 modes in one run; LASS_SPLIT=0 in every
+#     rocprofv3 pass: per-kernel durations and counters are only attributable when the two half-batches do not overlap)
 #  2. separate --pmc passes (FETCH_SIZE, WRITE_SIZE) of `bench.py --steps 1 --warmup 1` for f32 and bf16
 #  3. FETCH_SIZE / WRITE_SIZE calibration of the access shapes the kernels use (tools/fetch_calib.hip)
 #  4. SQ counters per conv launch of the pipeline itself (bench.py --steps 1, last step) for f32 and bf16 -> per-launch MFMA
@@ -13,7 +13,7 @@ O=$R/gpurun_out/prof_round
 rm -rf $O; mkdir -p $O
 LASS_SPLIT=0 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o x -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats.log || exit 1
 # f32 alone (the headline's kernels by name, no mode legs mixed in): rocprof average per launch vs the in-bench HIP events
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_f32only -o x -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --modes none > $O/bench_f32only_under_rocprof.json 2> $O/stats_f32only.log || exit 1
+LASS_SPLIT=0 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_f32only -o x -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --modes none > $O/bench_f32only_under_rocprof.json 2> $O/stats_f32only.log || exit 1
 cp $(find $O/stats_f32only -name '*kernel_stats.csv') $O/kernel_stats_f32only.csv
 for D in f32 bf16; do
   LASS_SPLIT=0 timeout -k 10 150 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_$D -o x -- python3 $R/bench.py --steps 1 --warmup 1 --dtype $D --modes none --no-cpu-baseline > $O/pmc_fetch_$D.json 2> $O/pmc_fetch_$D.log || exit 1
