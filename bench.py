@@ -332,7 +332,7 @@ def main():
     assert not check or torch.isfinite(out).all()
     # the same step launched eagerly (no hipGraph replay): what the HIP-event-instrumented loop below runs on
     eng.set_graph_replay(False)
-    dt_eager = timed(eng, args.steps, 1)
+    dt_eager = min(timed(eng, args.steps, 1), timed(eng, args.steps, 1))  # (min of two: a host hiccup shows in 80 launches / step)
     eng.set_graph_replay(True)
 
     # ---- the one exchange step: per-clip metric rows, all-gathered over the process group ---------------
@@ -460,7 +460,7 @@ def main():
     if "evaluator" in want:
         # SURVEY 8(f1), driver-timed: DCASEEvaluator.__call__ (dcase_evaluator.py:49-122) end to end on a synthetic validation set
         # of 260 clips (16 full batches + a ragged tail of 4): WAV decode on prefetch threads -> pinned staging -> H2D -> device-side
-        # mixing at SNR -> lass_separate -> device-side SDR / SI-SDR -> means; 1 warm-up call, median of 3 timed calls, against the
+        # mixing at SNR -> lass_separate -> device-side SDR / SI-SDR -> means; 1 warm-up call, median of 5 timed calls, against the
         # headline separator rate of this same run
         import shutil
         import tempfile
@@ -474,17 +474,17 @@ def main():
             ev = DCASEEvaluator(16000, csv_path, os.path.join(tmp, "lass_validation"), batch_size=B)
             ev(plm)
             dts, outv = [], None
-            for _ in range(3):
+            for _ in range(5):
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 outv = ev(plm)
                 torch.cuda.synchronize()
                 dts.append(time.perf_counter() - t0)
-            dt_ev = sorted(dts)[1]
+            dt_ev = sorted(dts)[2]
             sep_rate = world * B * args.steps / dt
             modes["evaluator_e2e"] = {
                 "workload": f"DCASEEvaluator.__call__ on {n_ev} synthetic 10 s mixtures (WAV files -> decode -> mix at SNR -> separate "
-                            f"-> SDR/SDRi/SI-SDR means), batch {B}, ragged tail of {n_ev % B}; 1 warm-up call, median of 3",
+                            f"-> SDR/SDRi/SI-SDR means), batch {B}, ragged tail of {n_ev % B}; 1 warm-up call, median of 5 (the decode threads share the box's CPUs: single calls scatter by 20 %)",
                 "clips_s": n_ev / dt_ev, "calls_s": [n_ev / d for d in dts], "separator_clips_s": sep_rate,
                 "evaluator_over_separator": n_ev / dt_ev / sep_rate,
                 "mean_sisdr_sdri_sdr": [float(v) for v in outv]}

@@ -39,11 +39,15 @@ for graph in (False, True):
         if not torch.equal(o, ref):
             bad += 1
             print(mode, "graph" if graph else "eager", "call", i, "differs: clips", torch.nonzero((o != ref).any(1))[:, 0].tolist(), flush=True)
-for e, name in ((e0, "unsplit"), (e1, "split")):
-    for _ in range(5): e.separate(x, cond)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(20): e.separate(x, cond)
-    torch.cuda.synchronize()
-    print(mode, name, "%.3f ms/step  %.0f clips/s" % ((time.perf_counter() - t0) / 20 * 1e3, B * 20 / (time.perf_counter() - t0)), flush=True)
+out = torch.empty_like(ref)
+for graph in (True, False):
+    for e, name in ((e0, "unsplit"), (e1, "split")):
+        e.set_graph_replay(graph)
+        for _ in range(5): e.separate(x, cond, out=out)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(20): e.separate(x, cond, out=out)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print(mode, name, "graph replay" if graph else "eager launches", "%.3f ms/step  %.0f clips/s" % (dt / 20 * 1e3, B * 20 / dt), flush=True)
 print(mode, "calls differing from the unsplit run:", bad, "of", 2 * calls, flush=True)
 sys.exit(1 if bad else 0)
