@@ -332,7 +332,7 @@ def main():
     assert not check or torch.isfinite(out).all()
     # the same step launched eagerly (no hipGraph replay): what the HIP-event-instrumented loop below runs on
     eng.set_graph_replay(False)
-    dt_eager = min(timed(eng, args.steps, 1), timed(eng, args.steps, 1))  # (min of two: a host hiccup shows in 80 launches / step)
+    dt_eager = min(timed(eng, args.steps, 1), timed(eng, args.steps, 1))  # (the faster of two passes: a host hiccup shows at 40 launches per step)
     eng.set_graph_replay(True)
 
     # ---- the one exchange step: per-clip metric rows, all-gathered over the process group ---------------
@@ -521,9 +521,9 @@ def main():
                        "note": "ms_per_step / value: the timed loop replays ONE captured hipGraph of the ~40 launches per "
                                "step; eager_ms_per_step: the same loop with replay switched off; kernel_ms_per_step / "
                                "class_ms_per_step: a third, eager loop with HIP events around every kernel class (their sum = "
-                               "profiled_ms_per_step: events add the drain between classes).  half_batch_overlap: the step "
-                               "runs as two half-batches on two streams (LASS_SPLIT; DESIGN.md 5b) - "
-                               "never in the profiled loop, whose classes must not overlap"},
+                               "profiled_ms_per_step: events add the drain between classes).  half_batch_overlap: the replayed "
+                               "graph runs the step as two half-batches on two branches (LASS_SPLIT; DESIGN.md 5b); the eager and "
+                               "the profiled loop launch it unsplit"},
             "roofline": {"bound": "mfma", "kernel": kernel,
                          "achieved": head["executed_tflops"], "peak": head["peak_tflops"], "unit": "TFLOP/s",
                          "frac": head["frac"],

@@ -102,11 +102,12 @@ int lass_workspace_bytes(const lass_ctx* ctx, int B, int L, size_t* bytes);
 /* The hot path.  mixture (B,L) f32, condition (B,512) f32 -> out (B,L) f32.
  * Replaces: ResUNet30.forward(input_dict)["waveform"] (resunet.py:640-653) with mixture/out squeezed of their
  * singleton channel axis.
- * Scheduling: an even batch of >= 8 clips runs as two independent half-batches (LASS_SPLIT=0 switches it off), the
- * second on an internal stream forked from / joined to `stream` by events, so that one half's small launches and
- * launch tails overlap the other half's full-size ones.  Clips are independent: the results are bit-identical to the
- * unsplit run, and `stream` still orders the whole call.  lass_workspace_bytes already accounts for it;
- * lass_workspace_tensor reports LASS_ERR_STATE for such a batch (its workspace holds two half-batch layouts). */
+ * Scheduling: the hipGraph that replays a recurring call runs an even batch of >= 8 clips as two independent
+ * half-batches on two branches, so that one half's small launches and launch tails overlap the other half's
+ * full-size ones (LASS_SPLIT=0: never; =2: eager launches too, the second half on an internal stream forked from /
+ * joined to `stream` by events).  Clips are independent: the results are bit-identical to the unsplit run, and `stream`
+ * still orders the whole call.  lass_workspace_bytes already accounts for it; lass_workspace_tensor reports
+ * LASS_ERR_STATE for such a batch (its workspace may hold two half-batch layouts). */
 int lass_separate(lass_ctx* ctx, const float* mixture, const float* condition, float* out, int B, int L,
                   void* workspace, size_t workspace_bytes, void* stream);
 

@@ -146,7 +146,10 @@ struct lass_ctx {
     // independent: eval-mode BN) - the second on `s2`, forked from / joined to the caller's stream by events - so that one
     // half's small launches (the 16-/8-bin layers: a few hundred workgroups) and launch tails run beside the other half's
     // full-size launches.  Same kernels, same per-clip arithmetic (bit-identical: batch invariance), same workspace size.
-    // Measured: bf16 +3.4 %, f32 +0.5 ... +2.1 % depending on the box, split-bf16 +1.1 %.  LASS_SPLIT=0 switches it off.
+    // Measured: bf16 +3.4 %, f32 +0.5 ... +2.1 % depending on the box, split-bf16 +1.1 %.
+    // 1 (default): only inside the captured hipGraph that lass_separate replays - an EAGER two-stream launch depends on the
+    // process having a free hardware queue for `s2` (with an RCCL communicator alive in the process it measured 8 % SLOWER than
+    // the unsplit launch, without one 2 % faster; a graph's branches do not care).  LASS_SPLIT=2: eager launches too; 0: never.
     // DESIGN.md section 5b has the measurements and the co-residency hazard found on the way.
     int split_batch = 1;
     hipStream_t s2 = nullptr;
@@ -676,9 +679,7 @@ void drop_graphs(lass_ctx* c) {
 }
 
 // A batch is split into two overlapping half-batches when it is large enough for each half to fill the GPU on its own
-bool split_halves(const lass_ctx* c, int B) {
-    return c->split_batch > 0 && !c->profiling && B >= 8 && (B % 2) == 0;
-}
+bool split_halves(const lass_ctx* c, int B) { return c->split_batch > 0 && !c->profiling && B >= 8 && (B % 2) == 0; }
 
 const ResBlock* find_block(const lass_ctx* c, const std::string& prefix) {
     for (const auto& rb : c->enc) if (rb.prefix == prefix) return &rb;
@@ -729,7 +730,7 @@ static int create_impl(lass_ctx** out, int device_id, const Geometry& geom) {
     if (const char* e = getenv("LASS_FUSE_BLOCK")) c->fuse_block = atoi(e) != 0;
     if (const char* e = getenv("LASS_FUSE_UP")) c->fuse_up = atoi(e) != 0;
     if (const char* e = getenv("LASS_WINO4")) c->wino4_mincin = atoi(e);
-    if (const char* e = getenv("LASS_SPLIT")) c->split_batch = atoi(e) != 0 ? 1 : 0;
+    if (const char* e = getenv("LASS_SPLIT")) c->split_batch = std::max(0, std::min(2, atoi(e)));
     if (const char* e = getenv("LASS_FUSE_PRECONV")) c->fuse_preconv = atoi(e) != 0;
     if (const char* e = getenv("LASS_GRAPH")) c->use_graph = atoi(e) != 0;
     c->prof.resize(P_COUNT);
@@ -1438,9 +1439,10 @@ static int separate_impl(lass_ctx* c, const float* mixture, const Components* co
 // lass_separate's launches, whole or as two overlapping half-batches (lass_ctx::split_batch).  Capture-safe: under stream
 // capture the event pair makes `s2` a parallel branch of the same graph.
 static int separate_any(lass_ctx* c, const float* mixture, const float* condition, float* out, int B, int L, void* workspace,
-                        size_t workspace_bytes, hipStream_t stream) {
+                        size_t workspace_bytes, hipStream_t stream, bool capturing) {
     Plan ph;
-    if (!c->finalized || !mixture || !condition || !out || !workspace || !split_halves(c, B) || make_plan(c, B / 2, L, &ph) ||
+    if (!c->finalized || !mixture || !condition || !out || !workspace || !split_halves(c, B) ||
+        (!capturing && c->split_batch < 2) || make_plan(c, B / 2, L, &ph) ||
         2 * ((ph.total + 255) / 256 * 256) > workspace_bytes)
         return separate_impl(c, mixture, nullptr, condition, out, B, L, workspace, workspace_bytes, stream, "lass_separate");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -1513,7 +1515,7 @@ int lass_separate(lass_ctx* c, const float* mixture, const float* condition, flo
                 Plan pl0;
                 if (!condition || !out || !workspace || make_plan(c, B, L, &pl0) || workspace_bytes < pl0.total ||
                     ((uintptr_t)workspace & 255) != 0)
-                    return separate_any(c, mixture, condition, out, B, L, workspace, workspace_bytes, (hipStream_t)stream);
+                    return separate_any(c, mixture, condition, out, B, L, workspace, workspace_bytes, (hipStream_t)stream, false);
                 slot->need = pl0.total;
                 if (split_halves(c, B)) {  // (checked again at capture time by separate_any: smaller workspaces run unsplit)
                     Plan ph0;
@@ -1525,7 +1527,7 @@ int lass_separate(lass_ctx* c, const float* mixture, const float* condition, flo
             if (!c->g_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->g_stream, hipStreamNonBlocking));
             bool ok = false;
             if (hipStreamBeginCapture(c->g_stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-                const int r = separate_any(c, mixture, condition, out, B, L, workspace, workspace_bytes, c->g_stream);
+                const int r = separate_any(c, mixture, condition, out, B, L, workspace, workspace_bytes, c->g_stream, true);
                 hipGraph_t graph = nullptr;
                 const hipError_t e = hipStreamEndCapture(c->g_stream, &graph);  // always ends the capture, also after a failure
                 if (r == 0 && e == hipSuccess && graph && hipGraphInstantiate(&slot->exec, graph, nullptr, nullptr, 0) == hipSuccess)
@@ -1546,7 +1548,7 @@ int lass_separate(lass_ctx* c, const float* mixture, const float* condition, flo
             c->err.clear();
         }
     }
-    return separate_any(c, mixture, condition, out, B, L, workspace, workspace_bytes, (hipStream_t)stream);
+    return separate_any(c, mixture, condition, out, B, L, workspace, workspace_bytes, (hipStream_t)stream, false);
 }
 
 int lass_set_graph_replay(lass_ctx* c, int enabled) {

@@ -635,7 +635,7 @@ def test_bf16_modes_full_size_metrics_vs_f32(synthetic_sd):
 
 @pytest.mark.parametrize("mode", ["bf16", "f32", "bf16x3"])
 def test_half_batch_overlap_is_bit_identical(synthetic_sd, monkeypatch, mode):
-    """lass_separate's two overlapping half-batches (the default for an even batch of >= 8 clips) against
+    """lass_separate's two overlapping half-batches (the captured graph's default for an even batch of >= 8 clips) against
     the unsplit run on the same 16 clips: the same bits, call after call, launched eagerly and as a replayed graph."""
     from lass_amd.resunet import ResUNet30
     B, L = 16, 160000
@@ -645,7 +645,7 @@ def test_half_batch_overlap_is_bit_identical(synthetic_sd, monkeypatch, mode):
     cond = torch.from_numpy(synthetic.make_condition(B)).to(DEV)
     engines = {}
     for split in ("1", "0"):
-        monkeypatch.setenv("LASS_SPLIT", split)
+        monkeypatch.setenv("LASS_SPLIT", "2" if split == "1" else "0")   # 2: eager launches split too (default: graphs only)
         m = ResUNet30(1, 1, 512)
         m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synthetic_sd.items()})
         engines[split] = m.to(DEV).eval().set_compute_dtype(mode).engine
