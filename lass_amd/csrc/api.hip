@@ -152,8 +152,9 @@ struct lass_ctx {
     // the unsplit launch, without one 2 % faster; a graph's branches do not care).  LASS_SPLIT=2: eager launches too; 0: never.
     // DESIGN.md section 5b has the measurements and the co-residency hazard found on the way.
     int split_batch = 1;
-    hipStream_t s2 = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int split_parts = 2;  // LASS_SPLIT_PARTS: 2 or 4 part-batches (each of at least 4 clips)
+    hipStream_t s2[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     unsigned long gen = 0;         // bumped by lass_finalize: a graph holds weight pointers
     long g_replays = 0, g_captures = 0;
     bool profiling = false;
@@ -680,6 +681,10 @@ void drop_graphs(lass_ctx* c) {
 
 // A batch is split into two overlapping half-batches when it is large enough for each half to fill the GPU on its own
 bool split_halves(const lass_ctx* c, int B) { return c->split_batch > 0 && !c->profiling && B >= 8 && (B % 2) == 0; }
+int split_parts(const lass_ctx* c, int B) {
+    if (!split_halves(c, B)) return 1;
+    return c->split_parts == 4 && B >= 16 && (B % 4) == 0 ? 4 : 2;
+}
 
 const ResBlock* find_block(const lass_ctx* c, const std::string& prefix) {
     for (const auto& rb : c->enc) if (rb.prefix == prefix) return &rb;
@@ -731,6 +736,7 @@ static int create_impl(lass_ctx** out, int device_id, const Geometry& geom) {
     if (const char* e = getenv("LASS_FUSE_UP")) c->fuse_up = atoi(e) != 0;
     if (const char* e = getenv("LASS_WINO4")) c->wino4_mincin = atoi(e);
     if (const char* e = getenv("LASS_SPLIT")) c->split_batch = std::max(0, std::min(2, atoi(e)));
+    if (const char* e = getenv("LASS_SPLIT_PARTS")) c->split_parts = atoi(e) == 4 ? 4 : 2;
     if (const char* e = getenv("LASS_FUSE_PRECONV")) c->fuse_preconv = atoi(e) != 0;
     if (const char* e = getenv("LASS_GRAPH")) c->use_graph = atoi(e) != 0;
     c->prof.resize(P_COUNT);
@@ -801,9 +807,11 @@ int lass_destroy(lass_ctx* c) {
     (void)hipDeviceSynchronize();  // no replay of a graph below is in flight any more
     drop_graphs(c);
     if (c->g_stream) (void)hipStreamDestroy(c->g_stream);
-    if (c->s2) (void)hipStreamDestroy(c->s2);
+    for (int i = 0; i < 3; ++i) {
+        if (c->s2[i]) (void)hipStreamDestroy(c->s2[i]);
+        if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
+    }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     (void)hipFree(c->tw2k);
     delete c;
     return 0;
@@ -1016,11 +1024,11 @@ int lass_workspace_bytes(const lass_ctx* c, int B, int L, size_t* bytes) {
     Plan pl;
     if (make_plan(c, B, L, &pl)) return LASS_ERR_ARG;  // B < 1, L <= 512 or L beyond the 32-bit per-clip addressing limit
     *bytes = pl.total;
-    if (split_halves(c, B)) {  // two half-batch plans side by side (they differ from the whole plan by alignment padding only)
+    if (const int P = split_parts(c, B); P > 1) {  // the part-batch plans side by side (they differ from the whole plan by alignment padding only)
         Plan ph;
-        if (make_plan(c, B / 2, L, &ph)) return LASS_ERR_ARG;
-        const size_t two = 2 * ((ph.total + 255) / 256 * 256);
-        if (two > *bytes) *bytes = two;
+        if (make_plan(c, B / P, L, &ph)) return LASS_ERR_ARG;
+        const size_t all = P * ((ph.total + 255) / 256 * 256);
+        if (all > *bytes) *bytes = all;
     }
     return 0;
 }
@@ -1441,27 +1449,33 @@ static int separate_impl(lass_ctx* c, const float* mixture, const Components* co
 static int separate_any(lass_ctx* c, const float* mixture, const float* condition, float* out, int B, int L, void* workspace,
                         size_t workspace_bytes, hipStream_t stream, bool capturing) {
     Plan ph;
-    if (!c->finalized || !mixture || !condition || !out || !workspace || !split_halves(c, B) ||
-        (!capturing && c->split_batch < 2) || make_plan(c, B / 2, L, &ph) ||
-        2 * ((ph.total + 255) / 256 * 256) > workspace_bytes)
+    const int P = c->finalized ? split_parts(c, B) : 1;
+    if (P < 2 || !mixture || !condition || !out || !workspace || (!capturing && c->split_batch < 2) || make_plan(c, B / P, L, &ph) ||
+        P * ((ph.total + 255) / 256 * 256) > workspace_bytes)
         return separate_impl(c, mixture, nullptr, condition, out, B, L, workspace, workspace_bytes, stream, "lass_separate");
     HIP_TRY(c, hipSetDevice(c->device));
-    if (!c->s2) {
-        HIP_TRY(c, hipStreamCreateWithFlags(&c->s2, hipStreamNonBlocking));
-        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-    }
-    const int h = B / 2;
-    const size_t half_ws = (ph.total + 255) / 256 * 256;
+    if (!c->ev_fork) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    for (int i = 0; i < P - 1; ++i)
+        if (!c->s2[i]) {
+            HIP_TRY(c, hipStreamCreateWithFlags(&c->s2[i], hipStreamNonBlocking));
+            HIP_TRY(c, hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
+        }
+    const int h = B / P;
+    const size_t part_ws = (ph.total + 255) / 256 * 256;
     HIP_TRY(c, hipEventRecord(c->ev_fork, stream));
-    HIP_TRY(c, hipStreamWaitEvent(c->s2, c->ev_fork, 0));
-    const int r = separate_impl(c, mixture, nullptr, condition, out, h, L, workspace, half_ws, stream, "lass_separate");
-    const int r2 = separate_impl(c, mixture + (size_t)h * L, nullptr, condition + (size_t)h * LASS_COND, out + (size_t)h * L, h, L,
-                                 (char*)workspace + half_ws, half_ws, c->s2, "lass_separate");
-    // the join is recorded even after a failure: a capturing stream must get its branch back
-    HIP_TRY(c, hipEventRecord(c->ev_join, c->s2));
-    HIP_TRY(c, hipStreamWaitEvent(stream, c->ev_join, 0));
-    return r ? r : r2;
+    for (int i = 0; i < P - 1; ++i) HIP_TRY(c, hipStreamWaitEvent(c->s2[i], c->ev_fork, 0));
+    int r = 0;
+    for (int i = 0; i < P; ++i) {
+        const int ri = separate_impl(c, mixture + (size_t)i * h * L, nullptr, condition + (size_t)i * h * LASS_COND, out + (size_t)i * h * L,
+                                     h, L, (char*)workspace + i * part_ws, part_ws, i ? c->s2[i - 1] : stream, "lass_separate");
+        if (!r) r = ri;
+    }
+    // the joins are recorded even after a failure: a capturing stream must get its branches back
+    for (int i = 0; i < P - 1; ++i) {
+        HIP_TRY(c, hipEventRecord(c->ev_join[i], c->s2[i]));
+        HIP_TRY(c, hipStreamWaitEvent(stream, c->ev_join[i], 0));
+    }
+    return r;
 }
 
 int lass_separate(lass_ctx* c, const float* mixture, const float* condition, float* out, int B, int L, void* workspace,
@@ -1517,10 +1531,10 @@ int lass_separate(lass_ctx* c, const float* mixture, const float* condition, flo
                     ((uintptr_t)workspace & 255) != 0)
                     return separate_any(c, mixture, condition, out, B, L, workspace, workspace_bytes, (hipStream_t)stream, false);
                 slot->need = pl0.total;
-                if (split_halves(c, B)) {  // (checked again at capture time by separate_any: smaller workspaces run unsplit)
+                if (const int P = split_parts(c, B); P > 1) {  // (checked again at capture time by separate_any: smaller workspaces run unsplit)
                     Plan ph0;
-                    if (!make_plan(c, B / 2, L, &ph0) && 2 * ((ph0.total + 255) / 256 * 256) <= workspace_bytes)
-                        slot->need = std::max(slot->need, 2 * ((ph0.total + 255) / 256 * 256));
+                    if (!make_plan(c, B / P, L, &ph0) && P * ((ph0.total + 255) / 256 * 256) <= workspace_bytes)
+                        slot->need = std::max(slot->need, P * ((ph0.total + 255) / 256 * 256));
                 }
             }
             HIP_TRY(c, hipSetDevice(c->device));
