@@ -667,6 +667,34 @@ def test_half_batch_overlap_is_bit_identical(synthetic_sd, monkeypatch, mode):
         engines["1"].workspace_tensor("out_real", B, L)
 
 
+@pytest.mark.parametrize("B,L,parts", [(8, 25600, "2"), (10, 40000, "2"), (16, 16000, "4"), (9, 25600, "2")])
+def test_part_batches_at_ragged_shapes(synthetic_sd, monkeypatch, B, L, parts):
+    """The part-batch schedule at batch sizes whose parts are odd / minimal, at short clips, with four parts, and at an odd
+    batch (which must simply run unsplit): eager two-stream launches (LASS_SPLIT=2) and the replayed graph against LASS_SPLIT=0,
+    bit for bit, in bf16 mode (every blocked-layout hand-over is in play there)."""
+    from lass_amd.resunet import ResUNet30
+    _, mix = synthetic.make_mixtures(B, L)
+    x = torch.from_numpy(mix).to(DEV)
+    cond = torch.from_numpy(synthetic.make_condition(B)).to(DEV)
+    engines = {}
+    monkeypatch.setenv("LASS_SPLIT_PARTS", parts)
+    for split in ("2", "0"):
+        monkeypatch.setenv("LASS_SPLIT", split)
+        m = ResUNet30(1, 1, 512)
+        m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synthetic_sd.items()})
+        engines[split] = m.to(DEV).eval().set_compute_dtype("bf16").engine
+    ref = engines["0"].separate(x, cond).clone()
+    assert torch.isfinite(ref).all() and float(ref.abs().max()) > 1e-3
+    out = torch.empty_like(ref)
+    for graph in (False, True):
+        engines["2"].set_graph_replay(graph)
+        for call in range(4):
+            out.zero_()
+            engines["2"].separate(x, cond, out=out)
+            torch.cuda.synchronize()
+            assert torch.equal(out, ref), (B, L, parts, "graph" if graph else "eager", call)
+
+
 def test_front_end_is_exact_beside_a_bf16_separation():
     """Regression check for the co-residency hazard of DESIGN.md 5b: STFT front-end launches on one stream while lass_separate
     (bf16) runs on another.  With packed-f32 instructions in stft.hip about one launch in six came out wrong; as built by
