@@ -130,6 +130,40 @@ def test_hip_taps_vs_reference_fixture_g1(model, golden_dir):
     np.testing.assert_allclose(xc.cpu().numpy(), g["x_center"], rtol=0, atol=2e-4)
 
 
+def test_hip_taps_vs_oracle_every_element(model, oracle_sd):
+    """Every element of every intermediate the shipped f32 pipeline leaves in its workspace (all 7 skips, 6 pooled tensors,
+    the bottleneck, 6 transposed-conv halves, decoder blocks 1-5, the separated spectrum) against the oracle's tensor of the
+    same name, at L = 25 600 (161 -> 192 frames: F(4x4,3x3) levels, F(2x2,3x3) levels and the 6 x 8-bin bottom): the maximum
+    absolute deviation of each tensor must stay below 3e-5 of that tensor's largest magnitude - an isolated wrong pixel (a
+    tile edge, a halo rule, a fused-pool window) fails it; the samples-and-moments fixtures G1 / G4 hold the same tensors
+    to the reference's own values."""
+    from oracle import resunet as orr
+    B, L = 2, 25600
+    _, mix = synthetic.make_mixtures(B, L, first=8)
+    cond = synthetic.make_condition(B, seed=5)
+    eng = model.engine
+    eng.separate(torch.from_numpy(mix).to(DEV), torch.from_numpy(cond).to(DEV))
+    torch.cuda.synchronize()
+    taps = {}
+    orr.forward(oracle_sd, {"mixture": torch.from_numpy(mix)[:, None, :], "condition": torch.from_numpy(cond)}, taps=taps)
+    T = arch.frames_for(L)
+    names = ([f"encoder_block{i}" for i in range(1, 7)] + [f"encoder_block{i}.pool" for i in range(1, 7)] + ["conv_block7a"] +
+             [f"decoder_block{i}.up" for i in range(1, 7)] + [f"decoder_block{i}" for i in range(1, 6)] + ["out_real", "out_imag"])
+    worst = (0.0, None)
+    for name in names:
+        t = eng.workspace_tensor(name, B, L).clone().cpu()
+        ref = taps[name]
+        if name in ("out_real", "out_imag"):
+            t = t[:, :, :T]
+        if t.shape != ref.shape:   # the oracle keeps the frame padding / a channel axis the workspace tensor does not
+            ref = ref.reshape(t.shape) if ref.numel() == t.numel() else ref[..., :t.shape[-2], :t.shape[-1]]
+        assert t.shape == ref.shape, (name, t.shape, ref.shape)
+        rel = float((t - ref).abs().max()) / float(ref.abs().max())
+        worst = max(worst, (rel, name))
+        assert rel < 3e-5, (name, rel)
+    print("largest max-abs deviation / max-abs over the", len(names), "tensors:", worst)
+
+
 UPS_REST = [("decoder_block3", 384, 256, (2, 2), 6, 32), ("decoder_block4", 256, 128, (2, 2), 10, 64),
             ("decoder_block2", 384, 384, (2, 2), 3, 16)]
 
