@@ -509,6 +509,38 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
         pb.init_dma(lane, wave, y0, x0, p.H, p.W);
         pb.init_wdma(lane, p.Nw);
         __syncthreads();  // phase A has finished with the LDS
+#ifndef LASS_SC_TWO_BUFFERS
+        {
+            // A chunk of the 1x1 shortcut is ONE tap: NCO x NPX MFMAs (128 cycles) against a DMA round trip of a microsecond, and
+            // Cin2 / 16 = 2 ... 48 of them follow each other - a two-buffer pipeline pays the whole latency per chunk.  The
+            // chunks are small (image PB::IN_U4 + slab PB::W_U4 = 10 KB at 64 couts), so the region phase A leaves behind
+            // holds a RING of RING_D slots: RING_D chunks are requested up front, chunk ch + RING_D - 1 as soon as every wave is
+            // past chunk ch - 1 (one barrier per chunk), and a wave waits only until ITS pieces of chunk ch have landed
+            // (vector-memory operations complete in order: all but the `later * ops` youngest).
+            constexpr int SLOT = PB::IN_U4 + PB::W_U4;
+            constexpr int RING_D = PA_LDS / SLOT < 6 ? PA_LDS / SLOT : 6;
+            static_assert(RING_D >= 2, "the shortcut ring needs two slots");
+            int ops = 0;  // DMA instructions this wave issues per chunk (wave-uniform)
+#pragma unroll
+            for (int i = 0; i < PB::NPC; ++i) ops += (wave + 4 * i < PB::NPIECE) ? 1 : 0;
+#pragma unroll
+            for (int i = 0; i < PB::NWPC; ++i) ops += (wave + 4 * i < PB::NWPIECE) ? 1 : 0;
+            auto request = [&](int ch) {
+                const unsigned slot = img0 + (unsigned)((ch % RING_D) * SLOT * 16);
+                pb.issue_dma(r_rs, r_rs, (unsigned)(ch * 2 * HW) * 16u, slot, wave);
+                pb.issue_wdma(wd_rs, wdl_rs, (unsigned)(ch * 2 * p.Nw) * 16u, p.Nw, slot + (unsigned)(PB::IN_U4 * 16), wave);
+            };
+            for (int ch = 0; ch < RING_D && ch < nB; ++ch) request(ch);
+            for (int ch = 0; ch < nB; ++ch) {
+                const int issued = min(nB - 1, ch == 0 ? RING_D - 1 : ch + RING_D - 2);  // youngest chunk requested so far
+                wait_vmcnt_dyn((issued - ch) * ops);
+                lds_barrier();  // (no vmcnt drain) chunk ch is in LDS for every wave, and every wave is past chunk ch - 1
+                if (ch >= 1 && ch + RING_D - 1 < nB) request(ch + RING_D - 1);  // into the slot of chunk ch - 1
+                const uint4* slot = lds4 + (ch % RING_D) * SLOT;
+                PB::compute(slot, slot + PB::IN_U4, acc, lane, wave);
+            }
+        }
+#else   // the round-3 schedule (two buffers, one DMA round trip per chunk): -DLASS_SC_TWO_BUFFERS, for A/B
         pb.issue_dma(r_rs, r_rs, 0u, img0, wave);
         pb.issue_wdma(wd_rs, wdl_rs, 0u, p.Nw, wl0, wave);
         for (int ch = 0; ch < nB; ++ch) {
@@ -522,6 +554,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
             }
             PB::compute(lds4 + cur * PB::IN_U4, lds4 + 2 * PB::IN_U4 + cur * PB::W_U4, acc, lane, wave);
         }
+#endif
         } else {
             uint4* wl_b = lds4 + 2 * PB::IN_U4;
             const unsigned img0 = (unsigned)(size_t)(__attribute__((address_space(3))) uint4*)lds4;

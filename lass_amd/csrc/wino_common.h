@@ -15,6 +15,28 @@ __device__ __forceinline__ void wait_vmcnt() {  // all but the N youngest vector
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// the same with a wave-uniform run-time count (0 ... 15; anything larger waits for 15, which is merely stricter)
+__device__ __forceinline__ void wait_vmcnt_dyn(int n) {
+    switch (n) {
+        case 0: wait_vmcnt<0>(); break;
+        case 1: wait_vmcnt<1>(); break;
+        case 2: wait_vmcnt<2>(); break;
+        case 3: wait_vmcnt<3>(); break;
+        case 4: wait_vmcnt<4>(); break;
+        case 5: wait_vmcnt<5>(); break;
+        case 6: wait_vmcnt<6>(); break;
+        case 7: wait_vmcnt<7>(); break;
+        case 8: wait_vmcnt<8>(); break;
+        case 9: wait_vmcnt<9>(); break;
+        case 10: wait_vmcnt<10>(); break;
+        case 11: wait_vmcnt<11>(); break;
+        case 12: wait_vmcnt<12>(); break;
+        case 13: wait_vmcnt<13>(); break;
+        case 14: wait_vmcnt<14>(); break;
+        default: wait_vmcnt<15>(); break;
+    }
+}
+
 typedef int v4i32 __attribute__((ext_vector_type(4)));
 
 // Workgroup -> (spatial tile bx, cout block by, clip bz) from a 1-D grid.  Workgroups are dealt round-robin over the 8
