@@ -3,13 +3,13 @@
 set -e
 cd "$(dirname "$0")/../lass_amd/csrc"
 SRC="api.hip conv.hip wino.hip wino32.hip wino4.hip conv_bf16.hip conv_bf16_fused.hip stft.hip misc.hip"
-hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared -o liblass_hip.so $SRC -Rpass-analysis=kernel-resource-usage 2> build.log || { grep -E "error" build.log | head -20; exit 1; }
+hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -fno-slp-vectorize -shared -o liblass_hip.so $SRC -Rpass-analysis=kernel-resource-usage 2> build.log || { grep -E "error" build.log | head -20; exit 1; }
 python3 - <<'PY'
 import sys; sys.path.insert(0, "../..")
 import __graft_entry__ as g
 open(g.STAMP, "w").write(g._src_hash())   # keep build()'s staleness stamp in step with this manual build
 PY
-if [ "$1" = "diag" ]; then hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared -DLASS_CONV_DIAG -o liblass_hip_diag.so $SRC 2>&1 | grep -E "error" || true; fi
+if [ "$1" = "diag" ]; then hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -fno-slp-vectorize -shared -DLASS_CONV_DIAG -o liblass_hip_diag.so $SRC 2>&1 | grep -E "error" || true; fi
 python3 - <<'PY'
 import re
 txt=open('build.log').read()

@@ -10,7 +10,7 @@ pids=()
 for s in $SRC; do
   o=.obj/${s%.hip}.o
   if [ ! -f $o ] || [ $s -nt $o ] || [ $NEWEST_H -nt $o ]; then
-    ( hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -c $s -o $o 2> .obj/${s%.hip}.log || { grep -E "error" .obj/${s%.hip}.log | head -20; exit 1; } ) &
+    ( hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -fno-slp-vectorize -c $s -o $o 2> .obj/${s%.hip}.log || { grep -E "error" .obj/${s%.hip}.log | head -20; exit 1; } ) &
     pids+=($!)
   fi
 done
@@ -22,7 +22,7 @@ if [ "$1" = "diag" ]; then  # diagnostic library (-DLASS_CONV_DIAG in the files 
   for s in $SRC; do
     b=${s%.hip}
     if echo " ${2:-api wino32} " | grep -q " $b "; then
-      hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -DLASS_CONV_DIAG -c $s -o .obj/diag/$b.o 2> .obj/diag/$b.log || { grep error .obj/diag/$b.log | head; exit 1; }
+      hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -fno-slp-vectorize -DLASS_CONV_DIAG -c $s -o .obj/diag/$b.o 2> .obj/diag/$b.log || { grep error .obj/diag/$b.log | head; exit 1; }
       DOBJS="$DOBJS .obj/diag/$b.o"
     else DOBJS="$DOBJS .obj/$b.o"; fi
   done
