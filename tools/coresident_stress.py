@@ -17,7 +17,6 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-os.environ["LASS_SPLIT"] = "0"
 from lass_amd import synthetic  # noqa: E402
 from lass_amd.resunet import ResUNet30  # noqa: E402
 
@@ -32,7 +31,15 @@ def run(mode="bf16", nrep=120, trials=3, verbose=True):
     sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synthetic.make_state_dict().items()}
     m = ResUNet30(1, 1, 512)
     m.load_state_dict(sd)
-    e = m.cuda().eval().set_compute_dtype(mode).engine
+    saved = os.environ.get("LASS_SPLIT")
+    os.environ["LASS_SPLIT"] = "0"  # read when the context is created: stream A runs ONE ordinary unsplit separation
+    try:
+        e = m.cuda().eval().set_compute_dtype(mode).engine
+    finally:
+        if saved is None:
+            del os.environ["LASS_SPLIT"]
+        else:
+            os.environ["LASS_SPLIT"] = saved
     e.set_graph_replay(False)
     ref = [t.clone() for t in e.front_end(xb)]
     oa = e.separate(xa, cond).clone()
