@@ -112,11 +112,14 @@ struct Phase16 {
     }
     // w_rs / wl_rs: weight matrix (hi / lo) from column n0 on; wb: byte offset of the chunk's slab [tap][octet][Cout];
     // wl_addr: LDS byte address of the weight buffer to fill
+    // [P0, P1): the pieces to request (the whole slab by default; HALF_SLAB requests taps 0-4 and taps 5-8 separately)
+    static constexpr int H0_PIECES = (TAPS == 9) ? 5 * 2 / RPP : NWPIECE;  // pieces of taps 0-4
+    template <int P0 = 0, int P1 = NWPIECE>
     __device__ __forceinline__ void issue_wdma(v4i32 w_rs, v4i32 wl_rs, unsigned wb, int Cout, unsigned wl_addr, int wave) {
 #pragma unroll
         for (int i = 0; i < NWPC; ++i) {
-            const int piece = wave + 4 * i;  // wave-uniform
-            if (piece < NWPIECE) {
+            const int piece = P0 + wave + 4 * i;  // wave-uniform
+            if (piece < P1) {
                 const unsigned soff = wb + (unsigned)(piece * RPP * Cout) * 16u;
                 lds_dma_16B(w_rs, wvo, soff, wl_addr + (unsigned)piece * 1024u);
                 if (SPLIT == 2) lds_dma_16B(wl_rs, wvo, soff, wl_addr + (unsigned)(W1_U4 * 16) + (unsigned)piece * 1024u);
@@ -209,6 +212,7 @@ struct Phase16 {
             if (SPLIT == 2) wl[W1_U4 + e] = wv[1][i];
         }
     }
+    template <int T0 = 0, int T1 = TAPS>
     __device__ __forceinline__ static void compute(const uint4* lds, const uint4* wl, f32x16 (&acc)[NCO][NPX], int lane,
                                                    int wave) {
         const int h = lane >> 5, j = lane & 31;
@@ -217,7 +221,7 @@ struct Phase16 {
         const bf16x8* abase = reinterpret_cast<const bf16x8*>(wl) + h * NT + j;
         if (SPLIT == 2) {
 #pragma unroll
-            for (int tap = 0; tap < TAPS; ++tap) {
+            for (int tap = T0; tap < T1; ++tap) {
                 bf16x8 ah[NCO], al[NCO], bh[NPX], bl[NPX];
 #pragma unroll
                 for (int co = 0; co < NCO; ++co) {
@@ -253,10 +257,10 @@ struct Phase16 {
                 bb[px] = bbase[(px * PH + (TAPS == 9 ? tap / 3 : 0)) * IP + (TAPS == 9 ? tap % 3 : 0)];
         };
 #pragma unroll
-        for (int t = 0; t < PFD && t < TAPS; ++t) rd(t, a[t], b[t]);
+        for (int t = T0; t < T0 + PFD && t < T1; ++t) rd(t, a[t % (PFD + 1)], b[t % (PFD + 1)]);
 #pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
-            if (tap + PFD < TAPS) rd(tap + PFD, a[(tap + PFD) % (PFD + 1)], b[(tap + PFD) % (PFD + 1)]);
+        for (int tap = T0; tap < T1; ++tap) {
+            if (tap + PFD < T1) rd(tap + PFD, a[(tap + PFD) % (PFD + 1)], b[(tap + PFD) % (PFD + 1)]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int co = 0; co < NCO; ++co)
@@ -274,8 +278,19 @@ struct MaxU {
     static constexpr int v = A > B ? A : B;
 };
 
+#ifndef LASS_HALF_SLAB
+#define LASS_HALF_SLAB 1
+#endif
+// The instantiations that run the half-slab schedule (see HALF_SLAB below) are built for three waves per SIMD: the conv2 +
+// shortcut kernels of the blocked-bf16 pipeline.  Measured per launch against the two-slab build: encoder conv2 + shortcut
+// (no spill at 154 registers) 0.906, decoder conv2 + shortcut (100 B of scratch) 0.981; the conv1 kernels, whose launch is
+// nearly all main phase, 1.022 - they keep two slabs and two workgroups per CU.
+template <int TAPS, int NCO, int NPX, int FLAGS, int SPLIT>
+constexpr bool half_slab_v = LASS_HALF_SLAB && (FLAGS & F_INBF16) != 0 && (FLAGS & F_PHASEB) != 0 && SPLIT == 1 && TAPS == 9 && NCO == 2 &&
+                             NPX == 2;
+
 template <int TAPS, int NCO, int NPX, int PW, int FLAGS, int SPLIT>
-__global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
+__global__ __launch_bounds__(NTHREADS, (half_slab_v<TAPS, NCO, NPX, FLAGS, SPLIT> ? 3 : 1)) void conv_bf16_kernel(ConvArgs p) {
     constexpr bool PRO = (FLAGS & F_PRO) != 0;
     constexpr bool HASB = (FLAGS & F_PHASEB) != 0;
     constexpr bool EPI = (FLAGS & F_EPIACT) != 0;
@@ -290,8 +305,14 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
     constexpr bool IN2BF = (FLAGS & F_IN2BF16) != 0;  // phase B reads the blocked bf16 raw copy by LDS-DMA
     using PB = Phase16<1, NCO, NPX, PW, false, SPLIT, false, IN2BF>;
     // DMA-fed phases: image double-buffered; the weight slab too when it is DMA'd (bf16), else one register-staged region
-    constexpr int PA_LDS = INBF ? 2 * PA::IN_U4 + (PA::WDMA ? 2 : 1) * PA::W_U4 : PA::LDS_U4;
-    constexpr int PB_LDS = IN2BF ? 2 * PB::IN_U4 + (PB::WDMA ? 2 : 1) * PB::W_U4 : PB::LDS_U4;
+    // HALF_SLAB (bf16, 64-cout tiles): ONE weight slab, refilled half by half (taps 0-4 while taps 5-8 of the previous chunk
+    // are contracted, taps 5-8 while taps 0-4 are) instead of two whole slabs: 40 KB instead of 59 KB of LDS per workgroup =
+    // THREE workgroups per CU.  Each half has half a chunk of MFMAs as cover instead of a whole one; the third workgroup more
+    // than pays for that (prologue, epilogue and shortcut of one workgroup now run beside TWO others' MFMA phases).
+    constexpr bool HALF_SLAB = half_slab_v<TAPS, NCO, NPX, FLAGS, SPLIT>;
+    static_assert(!HALF_SLAB || PA::WDMA, "half-slab schedule needs the DMA'd weight slab");
+    constexpr int PA_LDS = INBF ? 2 * PA::IN_U4 + (PA::WDMA && !HALF_SLAB ? 2 : 1) * PA::W_U4 : PA::LDS_U4;
+    constexpr int PB_LDS = IN2BF ? (PB::WDMA ? 4 : 2) * PB::IN_U4 + (PB::WDMA ? 4 : 1) * PB::W_U4 : PB::LDS_U4;  // WDMA: >= 4 ring slots
     constexpr int LDS_U4 = HASB ? MaxU<PA_LDS, PB_LDS>::v : PA_LDS;
     constexpr int PH = PA::PH, WROWS = PA::WROWS, PHT = PA::PHT, NT = PA::NT;
     constexpr bool MASK = (FLAGS & F_MASK) != 0;
@@ -412,6 +433,26 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
 #ifdef LASS_CONV_DIAG
         dg_t1 = clock64();
 #endif
+        if constexpr (HALF_SLAB) {
+            // (the prologue above has requested image 0 and the WHOLE slab of chunk 0)
+            int img_ops = 0;  // image DMA instructions of this wave per chunk (wave-uniform)
+#pragma unroll
+            for (int i = 0; i < PA::NPC; ++i) img_ops += (wave + 4 * i < PA::NPIECE) ? 1 : 0;
+            const uint4* slab = lds4 + 2 * PA::IN_U4;
+            for (int ch = 0; ch < nA; ++ch) {
+                const int cur = ch & 1;
+                const bool more = ch + 1 < nA;
+                wait_vmcnt<0>();  // image ch and taps 0-4 of chunk ch (chunk 0: the whole slab) have landed ...
+                lds_barrier();    // ... for every wave, and every wave is past taps 5-8 of chunk ch-1
+                if (ch > 0) pa.template issue_wdma<PA::H0_PIECES, PA::NWPIECE>(wd_rs, wdl_rs, (unsigned)(ch * TAPS * 2 * p.Nw) * 16u, p.Nw, wl0, wave);
+                if (more) pa.issue_dma(a_rs, al_rs, (unsigned)((ch + 1) * 2 * HW) * 16u, img0 + (unsigned)((cur ^ 1) * PA::IN_U4 * 16), wave);
+                PA::template compute<0, 5>(lds4 + cur * PA::IN_U4, slab, acc, lane, wave);
+                wait_vmcnt_dyn(more ? img_ops : 0);  // taps 5-8 have landed (the younger image pieces may still be under way)
+                lds_barrier();                       // ... for every wave, and every wave is past taps 0-4
+                if (more) pa.template issue_wdma<0, PA::H0_PIECES>(wd_rs, wdl_rs, (unsigned)((ch + 1) * TAPS * 2 * p.Nw) * 16u, p.Nw, wl0, wave);
+                PA::template compute<5, 9>(lds4 + cur * PA::IN_U4, slab, acc, lane, wave);
+            }
+        } else {
         for (int ch = 0; ch < nA; ++ch) {
             const int cur = ch & 1;
             wait_vmcnt<0>();   // this wave's pieces of chunk ch have landed
@@ -422,6 +463,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
                               wl0 + (unsigned)((cur ^ 1) * PA::W_U4 * 16), wave);
             }
             if (!(EXPF & 8)) PA::compute(lds4 + cur * PA::IN_U4, lds4 + 2 * PA::IN_U4 + cur * PA::W_U4, acc, lane, wave);
+        }
         }
         } else {
             // split operands: image of chunk ch+1 by LDS-DMA into the other buffer while chunk ch is contracted; weights
@@ -518,7 +560,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_bf16_kernel(ConvArgs p) {
             // past chunk ch - 1 (one barrier per chunk), and a wave waits only until ITS pieces of chunk ch have landed
             // (vector-memory operations complete in order: all but the `later * ops` youngest).
             constexpr int SLOT = PB::IN_U4 + PB::W_U4;
-            constexpr int RING_D = PA_LDS / SLOT < 6 ? PA_LDS / SLOT : 6;
+            constexpr int RING_D = LDS_U4 / SLOT < 6 ? LDS_U4 / SLOT : 6;
             static_assert(RING_D >= 2, "the shortcut ring needs two slots");
             int ops = 0;  // DMA instructions this wave issues per chunk (wave-uniform)
 #pragma unroll
