@@ -281,13 +281,14 @@ struct MaxU {
 #ifndef LASS_HALF_SLAB
 #define LASS_HALF_SLAB 1
 #endif
-// The instantiations that run the half-slab schedule (see HALF_SLAB below) are built for three waves per SIMD: the conv2 +
-// shortcut kernels of the blocked-bf16 pipeline.  Measured per launch against the two-slab build: encoder conv2 + shortcut
-// (no spill at 154 registers) 0.906, decoder conv2 + shortcut (100 B of scratch) 0.981; the conv1 kernels, whose launch is
-// nearly all main phase, 1.022 - they keep two slabs and two workgroups per CU.
+// The instantiations that run the half-slab schedule (see HALF_SLAB below) are built for three waves per SIMD: the encoder
+// blocks' conv2 + shortcut kernels of the blocked-bf16 pipeline.  Measured per launch against the two-slab build: encoder
+// conv2 + shortcut (154 registers, no spill) 0.906; decoder conv2 + shortcut, whose activated output needs two more tables,
+// 0.981 at 168 registers WITH 100 B of scratch per thread (0.2 GB of spill traffic per launch) - left at two slabs; the
+// conv1 kernels, whose launch is nearly all main phase, 1.022 - left at two slabs and two workgroups per CU.
 template <int TAPS, int NCO, int NPX, int FLAGS, int SPLIT>
-constexpr bool half_slab_v = LASS_HALF_SLAB && (FLAGS & F_INBF16) != 0 && (FLAGS & F_PHASEB) != 0 && SPLIT == 1 && TAPS == 9 && NCO == 2 &&
-                             NPX == 2;
+constexpr bool half_slab_v = LASS_HALF_SLAB && (FLAGS & F_INBF16) != 0 && (FLAGS & F_PHASEB) != 0 && (FLAGS & F_EPIACT) == 0 && SPLIT == 1 &&
+                             TAPS == 9 && NCO == 2 && NPX == 2;
 
 template <int TAPS, int NCO, int NPX, int PW, int FLAGS, int SPLIT>
 __global__ __launch_bounds__(NTHREADS, (half_slab_v<TAPS, NCO, NPX, FLAGS, SPLIT> ? 3 : 1)) void conv_bf16_kernel(ConvArgs p) {
