@@ -2,6 +2,7 @@
 without Lightning: a `.ckpt` is a plain torch-serialised dict whose 'state_dict' holds `ss_model.*` keys."""
 from __future__ import annotations
 
+import os
 from typing import Dict
 
 import torch
@@ -12,9 +13,22 @@ from .audiosep import AudioSep, get_model_class
 from .metrics import calculate_sdr, calculate_sisdr  # noqa: F401  (same import surface as the reference's utils)
 
 
+_PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def resolve_config(config_yaml: str) -> str:
+    """The reference resolves `config/audiosep_base.yaml` against the working directory (its scripts run from the repository
+    root, dcase_evaluator.py:126-130).  Same here; a relative path that is not there is looked up beside the package, where
+    the shipped `config/audiosep_base.yaml` lives, so `eval(evaluator, ckpt)` works from any directory."""
+    if os.path.isabs(config_yaml) or os.path.exists(config_yaml):
+        return config_yaml
+    shipped = os.path.join(_PKG_ROOT, config_yaml)
+    return shipped if os.path.exists(shipped) else config_yaml
+
+
 def parse_yaml(config_yaml: str) -> Dict:
     """utils.py:61-72 (SafeLoader: the reference config holds plain scalars/lists only)."""
-    with open(config_yaml, "r") as fr:
+    with open(resolve_config(config_yaml), "r") as fr:
         return yaml.load(fr, Loader=yaml.SafeLoader)
 
 

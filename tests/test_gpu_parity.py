@@ -406,6 +406,56 @@ def test_evaluator_matches_oracle(tmp_path, model, oracle_sd, L):
     assert sorted(sum(calls, [])) == sorted({f"synthetic tone cluster {i}" for i in range(4)})  # once per caption
 
 
+def test_eval_from_checkpoint_default_config(tmp_path, synthetic_sd, oracle_sd, capsys, monkeypatch):
+    """SURVEY §8 a14 / f2 end to end on the GPU: a Lightning-shaped `.ckpt` (`state_dict['ss_model.*']` next to
+    `query_encoder.*` keys and the torchlibrosa buffers a reference checkpoint carries, utils.py:387-398) goes through
+    `eval(evaluator, checkpoint_path)` with the reference's own call signature and DEFAULT `config_yaml`
+    (dcase_evaluator.py:126-145) into the HIP path; the returned triple equals the CPU oracle's evaluator and the printed
+    line is the reference's (`SDR: x, SDRi: y, SISDR: z`, dcase_evaluator.py:141-143)."""
+    import re
+    from lass_amd import evaluator as lev
+    from lass_amd.audiosep import PrecomputedQueryEncoder
+    from lass_amd.resunet import ResUNet30
+    from lass_amd.utils import get_ss_model
+    from oracle import evaluator as oev
+    n, L = 8, 32000
+    csv_path = synthetic.write_validation_set(str(tmp_path), n_clips=n, length=L)
+    ck = {"state_dict": {"ss_model." + k: torch.from_numpy(np.asarray(v)) for k, v in synthetic_sd.items()},
+          "epoch": 7, "global_step": 200000, "pytorch-lightning_version": "2.1.0"}
+    ck["state_dict"]["query_encoder.model.logit_scale_a"] = torch.zeros(())
+    ck["state_dict"]["query_encoder.model.text_projection.0.weight"] = torch.zeros(512, 768)
+    ck["state_dict"]["ss_model.base.stft.conv_real.weight"] = torch.zeros(513, 1, 1024)
+    ck["state_dict"]["ss_model.base.istft.conv_imag.weight"] = torch.zeros(1024, 1024, 1)
+    ckpt = os.path.join(str(tmp_path), "audiosep_16k,baseline,step=200000.ckpt")
+    torch.save(ck, ckpt)
+    monkeypatch.chdir(tmp_path)   # a working directory WITHOUT config/: the shipped config/audiosep_base.yaml must be found
+    ev = lev.DCASEEvaluator(sampling_rate=16000, eval_indexes=csv_path,
+                            audio_dir=os.path.join(str(tmp_path), "lass_validation"), batch_size=5)
+    sdr, sdri, sisdr = lev.eval(ev, ckpt, device="cuda")
+    out = capsys.readouterr().out
+    m = re.search(r"^SDR: (-?\d+\.\d{3}), SDRi: (-?\d+\.\d{3}), SISDR: (-?\d+\.\d{3})$", out, re.M)
+    assert m, out
+    assert [float(g) for g in m.groups()] == [round(sdr, 3), round(sdri, 3), round(sisdr, 3)]
+    assert "Evaluation on DCASE T9 synthetic validation set." in out and "Start Evaluation" in out
+    clips = [synthetic.make_clip(i, L) for i in range(n)]
+    conds = PrecomputedQueryEncoder().get_query_embed("text", [f"synthetic tone cluster {i % 4}" for i in range(n)]).numpy()
+    (o_sisdr, o_sdri, o_sdr), rows = oev.evaluate(oracle_sd, clips, conds)
+    np.testing.assert_allclose(ev.last_rows, rows, atol=0.01)
+    assert abs(sdr - o_sdr) < 0.01 and abs(sdri - o_sdri) < 0.01 and abs(sisdr - o_sisdr) < 0.01
+    # utils.py:326-353: the bare separator from the same default config; the checkpoint's weights load into it key for key
+    ss = get_ss_model("config/audiosep_base.yaml")
+    assert isinstance(ss, ResUNet30)
+    ss.load_state_dict({k[len("ss_model."):]: v for k, v in ck["state_dict"].items() if k.startswith("ss_model.")},
+                       strict=True)
+    ss = ss.to("cuda").eval()
+    _, mix = synthetic.make_mixtures(2, L)
+    cond = torch.from_numpy(synthetic.make_condition(2)).cuda()
+    wav = ss({"mixture": torch.from_numpy(mix)[:, None, :].cuda(), "condition": cond})["waveform"]
+    from oracle import resunet as orr
+    ref = orr.forward(oracle_sd, {"mixture": torch.from_numpy(mix)[:, None, :], "condition": cond.cpu()})["waveform"]
+    assert _rms(wav.cpu() - ref) <= 1e-5
+
+
 def test_mix_at_snr_vs_reference_formula(eng):
     """lass_mix_at_snr against dcase_evaluator.py:77-89 restated in numpy float32, incl. clips that need declipping."""
     rng = np.random.default_rng(3)

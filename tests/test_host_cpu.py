@@ -96,6 +96,30 @@ def test_checkpoint_reader(tmp_path):
     assert emb.shape == (3, 512) and torch.equal(emb[0], emb[1]) and abs(float(emb[2].norm()) - 1) < 1e-6
 
 
+def test_shipped_default_config(tmp_path, monkeypatch):
+    """`eval(evaluator, ckpt)` and `get_ss_model` default to `config/audiosep_base.yaml` (dcase_evaluator.py:126-130,
+    utils.py:326-353): the file ships with the repo, carries the reference's `model:` keys
+    (/root/reference/config/audiosep_base.yaml:23-30) and is found from any working directory."""
+    import inspect
+    from lass_amd import evaluator as lev
+    from lass_amd.resunet import ResUNet30
+    from lass_amd.utils import get_ss_model, parse_yaml, resolve_config
+    assert inspect.signature(lev.eval).parameters["config_yaml"].default == "config/audiosep_base.yaml"
+    monkeypatch.chdir(tmp_path)
+    cfg = parse_yaml("config/audiosep_base.yaml")
+    assert cfg["model"] == {"query_net": "CLAP", "condition_size": 512, "model_type": "ResUNet30", "input_channels": 1,
+                            "output_channels": 1, "resume_checkpoint": "", "use_text_ratio": 1.0}
+    assert cfg["data"]["sampling_rate"] == 16000 and cfg["data"]["stft_win_lengths"] == [256, 512, 2048]
+    assert cfg["data"]["loudness_norm"] == {"lower_db": -10, "higher_db": 10} and cfg["data"]["max_mix_num"] == 2
+    assert isinstance(get_ss_model("config/audiosep_base.yaml"), ResUNet30)
+    # a config in the working directory wins over the shipped one, as in the reference
+    os.makedirs("config")
+    open("config/audiosep_base.yaml", "w").write("model:\n  model_type: Nope\n  input_channels: 1\n  output_channels: 1\n  condition_size: 512\n")
+    assert resolve_config("config/audiosep_base.yaml") == "config/audiosep_base.yaml"
+    with pytest.raises(NotImplementedError):
+        get_ss_model("config/audiosep_base.yaml")
+
+
 def test_wav_roundtrip(tmp_path):
     from lass_amd.wavio import read_wav, write_wav_f32, write_wav_pcm16
     x = (np.random.default_rng(0).standard_normal(1000) * 0.2).astype(np.float32)
