@@ -41,8 +41,14 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=16, help="clips per GPU per step (BASELINE configs[1]: 16)")
-    ap.add_argument("--length", type=int, default=160000, help="samples per clip (10 s @ 16 kHz)")
+    ap.add_argument("--workload", choices=["resunet30", "multistft"], default="resunet30",
+                    help="resunet30 = BASELINE configs[1..3] (10 s @ 16 kHz clips, 16 per GPU); multistft = configs[4]'s "
+                         "per-GPU job: the multi-STFT ResUNet on 30 s @ 32 kHz clips (defaults --batch 1 --length 960000), "
+                         "the same timing / exchange protocol, so the driver's N=1,2,4,8 command scales it too")
+    ap.add_argument("--batch", type=int, default=None, help="clips per GPU per step (default 16: BASELINE configs[1]; "
+                                                            "1 with --workload multistft)")
+    ap.add_argument("--length", type=int, default=None, help="samples per clip (default 160000 = 10 s @ 16 kHz; "
+                                                             "960000 = 30 s @ 32 kHz with --workload multistft)")
     ap.add_argument("--dtype", choices=["f32", "bf16", "bf16x3"], default="f32",
                     help="headline arithmetic: f32 = BASELINE configs[1]; bf16 = configs[2] (bf16-MFMA convolutions)")
     ap.add_argument("--modes", default="auto",
@@ -57,7 +63,13 @@ def parse_args(argv=None):
                     help="cpu_baseline at B=16 with 1 warm-up + 3 timed forwards instead of SURVEY 8(d)'s 3 + 10 (~3 min of CPU time)")
     ap.add_argument("--cpu-full", action="store_true", help="(default since round 4; kept for old command lines)")
     ap.add_argument("--print-launch", action="store_true", help="N>1 parent: print the launch command and exit")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    ms = args.workload == "multistft"
+    if args.batch is None:
+        args.batch = 1 if ms else 16
+    if args.length is None:
+        args.length = 960000 if ms else 160000
+    return args
 
 
 # ---- N > 1 parent: never touches the GPU ------------------------------------------------------------------------------
@@ -272,8 +284,15 @@ def main():
             raise
         pg_error = f"{type(e).__name__}: {e}"
 
-    sd = synthetic.make_state_dict()
-    model = ResUNet30(1, 1, 512)
+    ms_workload = args.workload == "multistft"
+    rate = 32000.0 if ms_workload else 16000.0
+    if ms_workload:
+        from lass_amd.resunet_with_multistft import ResUNet30 as MultiSTFT
+        sd = synthetic.make_state_dict_ms()
+        model = MultiSTFT(1, 1, 512)
+    else:
+        sd = synthetic.make_state_dict()
+        model = ResUNet30(1, 1, 512)
     model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
     model = model.to(dev).eval().set_compute_dtype(args.dtype)
     B, L = args.batch, args.length
@@ -362,7 +381,7 @@ def main():
     psteps = max(1, min(args.profile_steps, args.steps))
     prof = profiled(eng, psteps)
 
-    rows = arch.conv_layer_table(arch.padded_frames(arch.frames_for(L)))
+    rows = (arch.ms_conv_layer_table if ms_workload else arch.conv_layer_table)(arch.padded_frames(arch.frames_for(L)))
     wino = os.environ.get("LASS_WINO", "1") != "0"
     w4thr = int(os.environ.get("LASS_WINO4", "32"))
     w4rows = arch.wino4_routed(rows, w4thr) if wino else set()
@@ -376,13 +395,15 @@ def main():
             exe, peak = exe_f32, PEAK_F32_MFMA_TFLOPS
         else:  # direct bf16 MFMA convolution; the split mode issues three MFMAs per product
             exe, peak = alg * (3.0 if dtype == "bf16x3" else 1.0), PEAK_BF16_MFMA_TFLOPS
-        byt = float(B) * arch.conv3x3_bytes_per_clip(L, 2 if dtype == "bf16" else 4)
+        # (the byte model is ResUNet30's layer table; for the multi-STFT workload the MFMA roofline alone is reported)
+        byt = None if ms_workload else float(B) * arch.conv3x3_bytes_per_clip(L, 2 if dtype == "bf16" else 4)
         return {"clips_s": world * B * steps / dt_mode, "ms_per_step": dt_mode / steps * 1e3,
                 "conv_ms": per_step * 1e3, "launches_per_step": launches / psteps,
                 "avg_launch_ms": ms / max(1, launches),
                 "executed_tflops": exe / per_step / 1e12, "algorithmic_tflops": alg / per_step / 1e12,
                 "peak_tflops": peak, "frac": exe / per_step / 1e12 / peak,
-                "hbm_algorithmic_gbs": byt / per_step / 1e9, "hbm_frac": byt / per_step / 1e9 / PEAK_HBM_GBS,
+                "hbm_algorithmic_gbs": None if byt is None else byt / per_step / 1e9,
+                "hbm_frac": None if byt is None else byt / per_step / 1e9 / PEAK_HBM_GBS,
                 "hbm_model": ("blocked bf16 activation storage between conv launches (2 B/element)" if dtype == "bf16"
                               else "f32 activation storage (4 B/element)") + ", ideal per-launch fusion (SURVEY 8d)",
                 "kernel_ms_per_step": {k: v[0] / psteps for k, v in prof_mode.items()}}
@@ -390,12 +411,16 @@ def main():
     head = mode_record(args.dtype, dt, args.steps, prof)
 
     def alg_bytes_launch_of(rec):
+        if ms_workload:
+            return None
         return float(B) * arch.conv3x3_bytes_per_clip(L, 2 if args.dtype == "bf16" else 4) / max(1.0, rec["launches_per_step"])
 
     modes = {}
     want = args.modes
     if want == "auto":
-        want = "bf16,bf16x3,multistft,evaluator" if (world == 1 and args.dtype == "f32") else "none"
+        want = "bf16,bf16x3,multistft,evaluator" if (world == 1 and args.dtype == "f32" and not ms_workload) else "none"
+    if ms_workload and any(x in want for x in ("multistft", "evaluator")):
+        raise SystemExit("--workload multistft: --modes takes bf16 / bf16x3 / none only")
     want = [x for x in want.split(",") if x and x != "none"]
     for m in [x for x in want if x not in ("multistft", "evaluator")]:
         model.set_compute_dtype(m)
@@ -408,9 +433,10 @@ def main():
         c1, r1 = e2.graph_stats()[1:]
         modes[m] = mode_record(m, dt_m, args.steps, profiled(e2, psteps))
         modes[m]["launch"] = {"captures": c1 - c0, "replays": r1 - r0, "half_batch_overlap": half_batch_overlap(m, B)}
-        alg_b = float(B) * arch.conv3x3_bytes_per_clip(L, 2 if m == "bf16" else 4) / max(1.0, modes[m]["launches_per_step"])
-        modes[m]["algorithmic_bytes_per_launch"] = alg_b
-        modes[m].update(traffic_fields(m, alg_b, (B, L) == (16, 160000)))
+        if not ms_workload:
+            alg_b = float(B) * arch.conv3x3_bytes_per_clip(L, 2 if m == "bf16" else 4) / max(1.0, modes[m]["launches_per_step"])
+            modes[m]["algorithmic_bytes_per_launch"] = alg_b
+            modes[m].update(traffic_fields(m, alg_b, (B, L) == (16, 160000)))
     if modes:
         model.set_compute_dtype(args.dtype)
 
@@ -494,7 +520,7 @@ def main():
     if rank == 0:
         alg_step, exe_step = conv_flops(rows, B, wino, w4rows)
         total_flops = 2.0 * B * sum(r["macs"] for r in rows)
-        traffic = traffic_fields(args.dtype, alg_bytes_launch_of(head), (B, L) == (16, 160000))
+        traffic = traffic_fields(args.dtype, alg_bytes_launch_of(head), (B, L) == (16, 160000) and not ms_workload)
         alg_bytes_launch = alg_bytes_launch_of(head)
         kernel = {"f32": (f"wino4_kernel<...> x{len(w4rows)} (Winograd F(4x4,3x3): {', '.join(sorted(w4rows))}) + wino32_kernel / "
                           f"wino_kernel x{26 - len(w4rows)} (F(2x2,3x3): the 16-/8-bin layers) on "
@@ -503,15 +529,20 @@ def main():
                           "transposed conv inside): direct 3x3 + fused 1x1 shortcuts on v_mfma_f32_32x32x16_bf16",
                   "bf16x3": "conv_bf16_kernel (split operands, 3 MFMAs per product) x26"}[args.dtype]
         res = {
-            "metric": "clips/sec (10s@16kHz)", "value": world * B * args.steps / dt, "unit": "clips/s",
+            "metric": "clips/sec (30s@32kHz)" if ms_workload else "clips/sec (10s@16kHz)", "value": world * B * args.steps / dt, "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"ResUNet30 separate() {'fp32' if args.dtype == 'f32' else args.dtype + ' MFMA convolutions'}, "
-                                   f"batch={B}/GPU, {L / 16000:.0f}s@16kHz clips, fixed precomputed condition embedding, "
-                                   f"seeded random-init weights (BASELINE configs[{1 if args.dtype == 'f32' else 2}]"
-                                   f"{'; configs[3] sharding' if world > 1 else ''})",
-                       "clips_per_gpu_per_step": B, "samples_per_clip": L, "parallelism": f"clip-sharded x{world}"},
-            "realtime_factor": world * B * args.steps / dt * (L / 16000.0),
+            "config": {"workload": (f"multi-STFT ResUNet30 (windows 256/512/2048 at n_fft 2048, authored spec: DESIGN.md section 9) "
+                                    f"{'fp32' if args.dtype == 'f32' else args.dtype + ' MFMA convolutions'}, batch={B}/GPU, "
+                                    f"{L / rate:.0f}s@32kHz clips, seeded random-init weights (BASELINE configs[4] per GPU; a clip "
+                                    f"here is {L / rate:.0f} s, not the metric's 10 s: see realtime_factor)") if ms_workload else
+                                   (f"ResUNet30 separate() {'fp32' if args.dtype == 'f32' else args.dtype + ' MFMA convolutions'}, "
+                                    f"batch={B}/GPU, {L / 16000:.0f}s@16kHz clips, fixed precomputed condition embedding, "
+                                    f"seeded random-init weights (BASELINE configs[{1 if args.dtype == 'f32' else 2}]"
+                                    f"{'; configs[3] sharding' if world > 1 else ''})"),
+                       "clips_per_gpu_per_step": B, "samples_per_clip": L, "sample_rate": int(rate),
+                       "parallelism": f"clip-sharded x{world}"},
+            "realtime_factor": world * B * args.steps / dt * (L / rate),
             "exchange": exch,
             "launch": {"hipgraph_replay": graph_on, "captures": graph_caps, "replays_in_headline_loops": graph_replays,
                        "half_batch_overlap": half_batch_overlap(args.dtype, B),

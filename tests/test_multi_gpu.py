@@ -175,6 +175,42 @@ def test_bench_self_launches_two_ranks_on_one_gpu():
 
 
 @pytest.mark.gpu
+def test_bench_two_ranks_at_the_full_configs3_per_rank_shape():
+    """The command the driver scales (`bench.py --gpus N`) at configs[3]'s FULL per-rank job - 16 clips of 10 s @ 16 kHz per
+    rank and step - with two ranks (gloo: both share the test box's one GPU; the driver's run uses RCCL, one GPU each).  The
+    exchange step gathers 2 x 16 rows, `value` is the whole job's clips over the max-over-ranks time."""
+    res = _bench_json(["--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "3", "--modes", "none",
+                       "--no-cpu-baseline"], timeout=1500)
+    assert res["n_gpus"] == 2 and res["steps"] == 3 and res["scaling"] == "weak" and res["dtype"] == "f32"
+    cfg = res["config"]
+    assert cfg["clips_per_gpu_per_step"] == 16 and cfg["samples_per_clip"] == 160000 and "configs[3] sharding" in cfg["workload"]
+    ex = res["exchange"]
+    assert ex["ranks"] == 2 and ex["rows"] == 32 and ex["allgather_ms"] > 0 and np.isfinite(ex["mean_sdr"])
+    assert res["value"] == pytest.approx(2 * 16 * 3 / (res["ms_per_step"] * 3e-3), rel=1e-6)
+    # two ranks time-share one GPU here: the whole-job rate stays near the one-GPU rate (each rank sees about half of it);
+    # on the driver's node every rank has its own GPU and the same line reads N x the N=1 value minus the exchange
+    assert 300 < res["value"] < 1400, res["value"]
+    assert 0 < res["roofline"]["frac"] <= 1.0 and "cpu_baseline" not in res and "modes" not in res
+
+
+@pytest.mark.gpu
+def test_bench_multistft_workload_two_ranks():
+    """configs[4]'s per-GPU job (multi-STFT ResUNet, ONE 30 s @ 32 kHz clip per rank and step) through the same bench command
+    and exchange step: `--workload multistft`, two gloo ranks on the one GPU."""
+    res = _bench_json(["--gpus", "2", "--backend", "gloo", "--workload", "multistft", "--steps", "2", "--warmup", "3",
+                       "--modes", "none", "--no-cpu-baseline"], timeout=1500)
+    assert res["n_gpus"] == 2 and res["metric"] == "clips/sec (30s@32kHz)"
+    cfg = res["config"]
+    assert cfg["clips_per_gpu_per_step"] == 1 and cfg["samples_per_clip"] == 960000 and cfg["sample_rate"] == 32000
+    assert "configs[4]" in cfg["workload"]
+    ex = res["exchange"]
+    assert ex["ranks"] == 2 and ex["rows"] == 2 and np.isfinite(ex["mean_sisdr"])
+    assert res["value"] == pytest.approx(2 * 1 * 2 / (res["ms_per_step"] * 2e-3), rel=1e-6)
+    assert res["realtime_factor"] == pytest.approx(res["value"] * 30.0, rel=1e-9)
+    assert 0 < res["roofline"]["frac"] <= 1.0 and res["roofline"]["traffic"] is None
+
+
+@pytest.mark.gpu
 def test_bench_single_rank_runs_the_rccl_exchange():
     """N=1: the per-clip metric rows still go through a torch.distributed all_gather on backend "nccl" (= RCCL), so the
     path configs[3] relies on executes on every bench run; roofline.frac is an executed-FLOP fraction (<= 1)."""
