@@ -278,6 +278,51 @@ struct MaxU {
     static constexpr int v = A > B ? A : B;
 };
 
+// Register-fed 1x1 contraction (round 5).  With the blocked bf16 layout [C/8][H][W][8] a lane's B fragment of
+// v_mfma_f32_32x32x16_bf16 - pixel j, input-channel octet 2c + khalf - is ONE aligned 16-byte unit of the tensor, and its A
+// fragment - cout j, the same octet - one 16-byte unit of the weight matrix [chunk][octet][Cout][8]: both go from global
+// memory straight into the MFMA operands (half a wave reads 512 contiguous bytes).  A 1x1 chunk is FOUR MFMAs per wave; fed
+// through LDS it cost a DMA round trip and a workgroup barrier per chunk (850-1 080 cycles: DESIGN.md section 8).  Two uses:
+//  * the 1x1 shortcut of a ConvBlockRes (resunet.py:163-165) rides in the 3x3 chunk loop - the fragments of shortcut chunks
+//    q*ch .. q*ch + q - 1 are requested while 3x3 chunk ch - 1 is contracted and consumed right behind chunk ch's barrier,
+//    8 MFMAs beside its 36 - instead of running as its own barriered phase behind the main loop;
+//  * the transposed convolutions (kernel = stride: a pointwise GEMM, resunet.py:216-224) run without LDS operands and
+//    without a barrier in their K loop.
+// Lane offsets: bvo[px] = byte offset of this lane's unit in octet khalf of a chunk (rows past the image: 0xC0000000 = the
+// descriptor's bounds check returns zeros), avo[co] = the same inside a chunk's weight rows.
+template <int NCO, int NPX, int PW>
+struct Reg1x1 {
+    static constexpr int PH = 32 / PW, WROWS = NPX * PH;
+    unsigned bvo[NPX], avo[NCO];
+    __device__ __forceinline__ void init(int lane, int wave, int y0, int x0, int H, int W, int Nw) {
+        const int h = lane >> 5, j = lane & 31, ty = j / PW, tx = j % PW;
+#pragma unroll
+        for (int px = 0; px < NPX; ++px) {
+            const int y = y0 + wave * WROWS + px * PH + ty;
+            bvo[px] = y < H ? 16u * (unsigned)((h * H + y) * W + x0 + tx) : 0xC0000000u;
+        }
+#pragma unroll
+        for (int co = 0; co < NCO; ++co) avo[co] = 16u * (unsigned)(h * Nw + co * 32 + j);
+    }
+    // chunk c of the tensor behind `in_rs` (one clip, HW pixels per octet plane) and of the weights behind `w_rs` (row pitch Nw)
+    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t in_rs, __amdgpu_buffer_rsrc_t w_rs, int c, int HW, int Nw,
+                                         bf16x8 (&a)[NCO], bf16x8 (&b)[NPX]) const {
+#pragma unroll
+        for (int co = 0; co < NCO; ++co)
+            a[co] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w_rs, (int)avo[co], (int)((unsigned)(c * 2 * Nw) * 16u), 0));
+#pragma unroll
+        for (int px = 0; px < NPX; ++px)
+            b[px] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(in_rs, (int)bvo[px], (int)((unsigned)(c * 2 * HW) * 16u), 0));
+    }
+    __device__ __forceinline__ static void mfma(const bf16x8 (&a)[NCO], const bf16x8 (&b)[NPX], f32x16 (&acc)[NCO][NPX]) {
+#pragma unroll
+        for (int co = 0; co < NCO; ++co)
+#pragma unroll
+            for (int px = 0; px < NPX; ++px)
+                acc[co][px] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[co], b[px], acc[co][px], 0, 0, 0);
+    }
+};
+
 #ifndef LASS_HALF_SLAB
 #define LASS_HALF_SLAB 1
 #endif
@@ -312,6 +357,15 @@ __global__ __launch_bounds__(NTHREADS, (half_slab_v<TAPS, NCO, NPX, FLAGS, SPLIT
     // than pays for that (prologue, epilogue and shortcut of one workgroup now run beside TWO others' MFMA phases).
     constexpr bool HALF_SLAB = half_slab_v<TAPS, NCO, NPX, FLAGS, SPLIT>;
     static_assert(!HALF_SLAB || PA::WDMA, "half-slab schedule needs the DMA'd weight slab");
+    // Round 5: 1x1 contractions whose operands are blocked bf16 go from global memory straight into the MFMA (Reg1x1):
+    // RF_MAIN = the whole K loop of a 1x1 kernel (transposed convs), RF_SC = the 1x1 shortcut folded into the 3x3 chunk loop
+    // (at most RF_Q shortcut chunks per 3x3 chunk; a launch with more falls back to the ring schedule behind the main loop).
+#ifndef LASS_RF1X1
+#define LASS_RF1X1 1
+#endif
+    constexpr bool RF_MAIN = LASS_RF1X1 && TAPS == 1 && INBF && PA::WDMA && !HASB;
+    constexpr bool RF_SC = LASS_RF1X1 && TAPS == 9 && HASB && IN2BF && INBF && PA::WDMA && PB::WDMA && !HALF_SLAB;
+    constexpr int RF_Q = 2;
     constexpr int PA_LDS = INBF ? 2 * PA::IN_U4 + (PA::WDMA && !HALF_SLAB ? 2 : 1) * PA::W_U4 : PA::LDS_U4;
     constexpr int PB_LDS = IN2BF ? (PB::WDMA ? 4 : 2) * PB::IN_U4 + (PB::WDMA ? 4 : 1) * PB::W_U4 : PB::LDS_U4;  // WDMA: >= 4 ring slots
     constexpr int LDS_U4 = HASB ? MaxU<PA_LDS, PB_LDS>::v : PA_LDS;
@@ -411,6 +465,7 @@ __global__ __launch_bounds__(NTHREADS, (half_slab_v<TAPS, NCO, NPX, FLAGS, SPLIT
                 for (int r = 0; r < 16; ++r)
                     acc[co][px][r] = BIAS ? lds_bias[co * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf] : 0.f;
     };
+    bool sc_folded = false;  // (wave-uniform) the 1x1 shortcut has been contracted inside the main loop
     if (INBF) {
         // Everything a chunk needs - the activation image and the weight slab - arrives by LDS-DMA into alternating
         // buffers while the previous chunk is contracted: no VGPRs, no VALU, no ds_write, ONE barrier per chunk.
@@ -419,6 +474,28 @@ __global__ __launch_bounds__(NTHREADS, (half_slab_v<TAPS, NCO, NPX, FLAGS, SPLIT
         const v4i32 al_rs = SPLIT == 2
                                 ? make_rsrc_words(reinterpret_cast<const char*>(p.in_bf16_lo) + (size_t)b * plane, (unsigned)plane)
                                 : a_rs;
+        if constexpr (RF_MAIN) {
+            // 1x1 main phase (the transposed convs) fed from registers: no LDS operands, no barrier in the K loop; a ring of
+            // RF_D chunks of fragments (16 bytes x (NCO + NPX) per lane and chunk) is kept in flight
+            Reg1x1<NCO, NPX, PW> rf;
+            rf.init(lane, wave, y0, x0, p.H, p.W, p.Nw);
+            const __amdgpu_buffer_rsrc_t x_rs = rs(reinterpret_cast<const char*>(p.in_bf16) + (size_t)b * plane, plane);
+            __syncthreads();  // epilogue tables visible
+            init_acc();
+            constexpr int RF_D = 4;
+            bf16x8 fa[RF_D][NCO], fb[RF_D][NPX];
+#pragma unroll
+            for (int s = 0; s < RF_D; ++s)
+                if (s < nA) rf.load(x_rs, wa_rs, s, HW, p.Nw, fa[s], fb[s]);
+            for (int ch = 0; ch < nA; ch += RF_D) {
+#pragma unroll
+                for (int s = 0; s < RF_D; ++s)
+                    if (ch + s < nA) {
+                        rf.mfma(fa[s], fb[s], acc);
+                        if (ch + s + RF_D < nA) rf.load(x_rs, wa_rs, ch + s + RF_D, HW, p.Nw, fa[s], fb[s]);
+                    }
+            }
+        } else
         if constexpr (PA::WDMA) {
         const unsigned wbytes = (unsigned)(((long)(p.Cin / KB) * TAPS * 2 * p.Nw - n0) * 16);
         const v4i32 wd_rs = make_rsrc_words(wa, wbytes);
@@ -454,17 +531,44 @@ __global__ __launch_bounds__(NTHREADS, (half_slab_v<TAPS, NCO, NPX, FLAGS, SPLIT
                 PA::template compute<5, 9>(lds4 + cur * PA::IN_U4, slab, acc, lane, wave);
             }
         } else {
+        // RF_SC: shortcut chunks q*ch + s (s < q) ride with 3x3 chunk ch.  Their fragments are requested one chunk ahead
+        // (ordinary loads the compiler tracks; the LDS-DMA is issued from asm and is invisible to it) and consumed right
+        // behind the barrier, BEFORE the next chunk's DMA is issued: hipcc waits vmcnt(0) in front of their first use, which
+        // at that point finds nothing outstanding - behind the DMA issue it would drain the next chunk's pieces.
+        Reg1x1<NCO, NPX, PW> rf;
+        bf16x8 sa[RF_SC ? RF_Q : 1][NCO], sb[RF_SC ? RF_Q : 1][NPX];
+        const int scq = RF_SC ? (nB + nA - 1) / nA : 0;
+        const bool fold = RF_SC && scq <= RF_Q;
+        const __amdgpu_buffer_rsrc_t r2_rs = RF_SC ? rs(reinterpret_cast<const char*>(p.in2_bf16) + (size_t)b * ((long)(p.Cin2 / 8) * HW * 16),
+                                                        (long)(p.Cin2 / 8) * HW * 16) : wa_rs;
+        auto sc_load = [&](int ch) {
+#pragma unroll
+            for (int s = 0; s < (RF_SC ? RF_Q : 0); ++s)
+                if (s < scq && ch * scq + s < nB) rf.load(r2_rs, wb_rs, ch * scq + s, HW, p.Nw, sa[s], sb[s]);
+        };
+        auto sc_mfma = [&](int ch) {
+#pragma unroll
+            for (int s = 0; s < (RF_SC ? RF_Q : 0); ++s)
+                if (s < scq && ch * scq + s < nB) rf.mfma(sa[s], sb[s], acc);
+        };
+        if (fold) {
+            rf.init(lane, wave, y0, x0, p.H, p.W, p.Nw);
+            sc_load(0);
+        }
         for (int ch = 0; ch < nA; ++ch) {
             const int cur = ch & 1;
             wait_vmcnt<0>();   // this wave's pieces of chunk ch have landed
             __syncthreads();   // ... everyone's have, and everyone has finished contracting chunk ch-1
+            if (fold) sc_mfma(ch);
             if (ch + 1 < nA) {
                 if (!(EXPF & 2)) pa.issue_dma(a_rs, al_rs, (unsigned)((ch + 1) * 2 * HW) * 16u, img0 + (unsigned)((cur ^ 1) * PA::IN_U4 * 16), wave);
                 if (!(EXPF & 1)) pa.issue_wdma(wd_rs, wdl_rs, (unsigned)((ch + 1) * TAPS * 2 * p.Nw) * 16u, p.Nw,
                               wl0 + (unsigned)((cur ^ 1) * PA::W_U4 * 16), wave);
+                if (fold) sc_load(ch + 1);
             }
             if (!(EXPF & 8)) PA::compute(lds4 + cur * PA::IN_U4, lds4 + 2 * PA::IN_U4 + cur * PA::W_U4, acc, lane, wave);
         }
+        sc_folded = fold;
         }
         } else {
             // split operands: image of chunk ch+1 by LDS-DMA into the other buffer while chunk ch is contracted; weights
@@ -539,7 +643,7 @@ __global__ __launch_bounds__(NTHREADS, (half_slab_v<TAPS, NCO, NPX, FLAGS, SPLIT
         }
     }
     if (!INBF) PA::compute(lds4, wl_a, acc, lane, wave);  // last chunk of phase A (the INBF loop contracts all of them)
-    if (HASB && IN2BF) {
+    if (HASB && IN2BF && !sc_folded) {
         // same schedule as the INBF main phase: image and weights by LDS-DMA into alternating buffers
         const long plane2 = (long)(p.Cin2 / 8) * HW * 16;
         const v4i32 r_rs = make_rsrc_words(reinterpret_cast<const char*>(p.in2_bf16) + (size_t)b * plane2, (unsigned)plane2);
@@ -624,7 +728,7 @@ __global__ __launch_bounds__(NTHREADS, (half_slab_v<TAPS, NCO, NPX, FLAGS, SPLIT
                 __syncthreads();
             }
         }
-    } else if (HASB) {
+    } else if (HASB && !IN2BF) {
         uint4* wl_b = lds4 + PB::IN_U4;
         __syncthreads();
         pb.store(lds4, wl_b, tid);
