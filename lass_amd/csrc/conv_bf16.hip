@@ -364,8 +364,8 @@ __global__ __launch_bounds__(NTHREADS, (half_slab_v<TAPS, NCO, NPX, FLAGS, SPLIT
 #define LASS_RF1X1 1
 #endif
     constexpr bool RF_MAIN = LASS_RF1X1 && TAPS == 1 && INBF && PA::WDMA && !HASB;
-    constexpr bool RF_SC = LASS_RF1X1 && TAPS == 9 && HASB && IN2BF && INBF && PA::WDMA && PB::WDMA && !HALF_SLAB;
-    constexpr int RF_Q = 2;
+    constexpr bool RF_SC = LASS_RF1X1 && TAPS == 9 && HASB && IN2BF && INBF && PA::WDMA && PB::WDMA;
+    constexpr int RF_Q = HALF_SLAB ? 1 : 2;  // (the half-slab kernels live within 168 registers: three workgroups per CU)
     constexpr int PA_LDS = INBF ? 2 * PA::IN_U4 + (PA::WDMA && !HALF_SLAB ? 2 : 1) * PA::W_U4 : PA::LDS_U4;
     constexpr int PB_LDS = IN2BF ? (PB::WDMA ? 4 : 2) * PB::IN_U4 + (PB::WDMA ? 4 : 1) * PB::W_U4 : PB::LDS_U4;  // WDMA: >= 4 ring slots
     constexpr int LDS_U4 = HASB ? MaxU<PA_LDS, PB_LDS>::v : PA_LDS;
@@ -511,26 +511,6 @@ __global__ __launch_bounds__(NTHREADS, (half_slab_v<TAPS, NCO, NPX, FLAGS, SPLIT
 #ifdef LASS_CONV_DIAG
         dg_t1 = clock64();
 #endif
-        if constexpr (HALF_SLAB) {
-            // (the prologue above has requested image 0 and the WHOLE slab of chunk 0)
-            int img_ops = 0;  // image DMA instructions of this wave per chunk (wave-uniform)
-#pragma unroll
-            for (int i = 0; i < PA::NPC; ++i) img_ops += (wave + 4 * i < PA::NPIECE) ? 1 : 0;
-            const uint4* slab = lds4 + 2 * PA::IN_U4;
-            for (int ch = 0; ch < nA; ++ch) {
-                const int cur = ch & 1;
-                const bool more = ch + 1 < nA;
-                wait_vmcnt<0>();  // image ch and taps 0-4 of chunk ch (chunk 0: the whole slab) have landed ...
-                lds_barrier();    // ... for every wave, and every wave is past taps 5-8 of chunk ch-1
-                if (ch > 0) pa.template issue_wdma<PA::H0_PIECES, PA::NWPIECE>(wd_rs, wdl_rs, (unsigned)(ch * TAPS * 2 * p.Nw) * 16u, p.Nw, wl0, wave);
-                if (more) pa.issue_dma(a_rs, al_rs, (unsigned)((ch + 1) * 2 * HW) * 16u, img0 + (unsigned)((cur ^ 1) * PA::IN_U4 * 16), wave);
-                PA::template compute<0, 5>(lds4 + cur * PA::IN_U4, slab, acc, lane, wave);
-                wait_vmcnt_dyn(more ? img_ops : 0);  // taps 5-8 have landed (the younger image pieces may still be under way)
-                lds_barrier();                       // ... for every wave, and every wave is past taps 0-4
-                if (more) pa.template issue_wdma<0, PA::H0_PIECES>(wd_rs, wdl_rs, (unsigned)((ch + 1) * TAPS * 2 * p.Nw) * 16u, p.Nw, wl0, wave);
-                PA::template compute<5, 9>(lds4 + cur * PA::IN_U4, slab, acc, lane, wave);
-            }
-        } else {
         // RF_SC: shortcut chunks q*ch + s (s < q) ride with 3x3 chunk ch.  Their fragments are requested one chunk ahead
         // (ordinary loads the compiler tracks; the LDS-DMA is issued from asm and is invisible to it) and consumed right
         // behind the barrier, BEFORE the next chunk's DMA is issued: hipcc waits vmcnt(0) in front of their first use, which
@@ -555,6 +535,34 @@ __global__ __launch_bounds__(NTHREADS, (half_slab_v<TAPS, NCO, NPX, FLAGS, SPLIT
             rf.init(lane, wave, y0, x0, p.H, p.W, p.Nw);
             sc_load(0);
         }
+        if constexpr (HALF_SLAB) {
+            // (the prologue above has requested image 0 and the WHOLE slab of chunk 0)
+            int img_ops = 0;  // image DMA instructions of this wave per chunk (wave-uniform)
+#pragma unroll
+            for (int i = 0; i < PA::NPC; ++i) img_ops += (wave + 4 * i < PA::NPIECE) ? 1 : 0;
+            const uint4* slab = lds4 + 2 * PA::IN_U4;
+            for (int ch = 0; ch < nA; ++ch) {
+                const int cur = ch & 1;
+                const bool more = ch + 1 < nA;
+                wait_vmcnt<0>();  // image ch and taps 0-4 of chunk ch (chunk 0: the whole slab) have landed ...
+                lds_barrier();    // ... for every wave, and every wave is past taps 5-8 of chunk ch-1
+                if (fold) sc_mfma(ch);
+                if (ch > 0) pa.template issue_wdma<PA::H0_PIECES, PA::NWPIECE>(wd_rs, wdl_rs, (unsigned)(ch * TAPS * 2 * p.Nw) * 16u, p.Nw, wl0, wave);
+                if (more) pa.issue_dma(a_rs, al_rs, (unsigned)((ch + 1) * 2 * HW) * 16u, img0 + (unsigned)((cur ^ 1) * PA::IN_U4 * 16), wave);
+                int sc_ops = 0;  // fragment loads of the next chunk's shortcut slots (younger than the pieces waited for below)
+                if (fold && more) {
+                    sc_load(ch + 1);
+#pragma unroll
+                    for (int s2 = 0; s2 < RF_Q; ++s2) sc_ops += (s2 < scq && (ch + 1) * scq + s2 < nB) ? NCO + NPX : 0;
+                }
+                PA::template compute<0, 5>(lds4 + cur * PA::IN_U4, slab, acc, lane, wave);
+                wait_vmcnt_dyn((more ? img_ops : 0) + sc_ops);  // taps 5-8 have landed (the younger image pieces / fragments may still be under way)
+                lds_barrier();                       // ... for every wave, and every wave is past taps 0-4
+                if (more) pa.template issue_wdma<0, PA::H0_PIECES>(wd_rs, wdl_rs, (unsigned)((ch + 1) * TAPS * 2 * p.Nw) * 16u, p.Nw, wl0, wave);
+                PA::template compute<5, 9>(lds4 + cur * PA::IN_U4, slab, acc, lane, wave);
+            }
+            sc_folded = fold;
+        } else {
         for (int ch = 0; ch < nA; ++ch) {
             const int cur = ch & 1;
             wait_vmcnt<0>();   // this wave's pieces of chunk ch have landed

@@ -29,7 +29,7 @@ def last_step(tag):
     s = max(i for i in idx if i < end[-1])
     return ks[s:end[-1] + 1]
 a, b = last_step("A"), last_step("B")
-short = lambda n: re.sub(r"\(.*", "", n)[:64]
+short = lambda n: re.sub(r"^void |\(.*", "", n)[:64]
 print("%-66s %9s   %-66s %9s" % ("A", "us", "B", "us"))
 for i in range(max(len(a), len(b))):
     ka = a[i] if i < len(a) else ("", 0.0); kb = b[i] if i < len(b) else ("", 0.0)
