@@ -228,6 +228,19 @@ int lass_sdr_stats(lass_ctx* ctx, const float* ref, const float* est, int B, int
 int lass_mix_at_snr(lass_ctx* ctx, float* source, const float* noise, const float* snr_db, float* mixture, int B, int L,
                     double* scratch, void* stream);
 
+/* Training-side data path ("next" row f4, mixer half; also the producer stage of the STFT pre-compute,
+ * scripts/precompute_stfts.py:352-681): SegmentMixer.__call__ + dynamic_loudnorm (data/waveform_mixers.py:19-92) on the
+ * device.  waveforms (B,L) -> mixture (B,L), segment (B,L).  For clip n:
+ *   noise = sum_{i=1}^{mix_num[n]-1} 10^(comp_db[n][i-1]/20) * (x_{(n+i)%B} / clamp(sqrt(E_{(n+i)%B} / max(E_n,1e-10)), 0.02, 50));
+ *   noise = 10^(noise_db[n]/20) * (noise / clamp(sqrt(E_noise / max(E_n,1e-10)), 0.02, 50));   E = mean(x^2)
+ *   mixture = x_n + noise;  if max|mixture| > 1: segment = x_n * 0.9/max, mixture *= 0.9/max, else segment = x_n.
+ * The reference draws mix_num = randint(2, max_mix_num) and the dB values = randint(lower_db, higher_db) with Python's
+ * `random`; here they are INPUTS (device arrays: mix_num int32 (B), comp_db f32 (B, max_comp), noise_db f32 (B)), so the
+ * host decides the draws (lass_amd.waveform_mixers.SegmentMixer draws them in the reference's order).
+ * max_comp = max_mix_num - 1 (1 ... 7); scratch: 4*B doubles; the three waveform buffers must be distinct. */
+int lass_segment_mix(lass_ctx* ctx, const float* waveforms, int B, int L, const int* mix_num, const float* comp_db, int max_comp,
+                     const float* noise_db, float* mixture, float* segment, double* scratch, void* stream);
+
 /* ---- instrumentation ---------------------------------------------------------------------------------------- */
 
 /* When enabled, lass_separate brackets each kernel class with HIP events on `stream` (costs a few us per launch).

@@ -24,6 +24,8 @@ SYMBOLS = [
     ("lass_stft_magphase", c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p]),
     ("lass_mix_at_snr", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    ("lass_segment_mix", c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_void_p]),
     ("lass_multi_stft", c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, POINTER(c_int), POINTER(c_void_p),
                                 POINTER(c_void_p), POINTER(c_void_p), c_void_p]),
     ("lass_graph_stats", c_int, [c_void_p, POINTER(c_long), POINTER(c_long)]),

@@ -1261,6 +1261,19 @@ int lass_mix_at_snr(lass_ctx* c, float* source, const float* noise, const float*
     return 0;
 }
 
+int lass_segment_mix(lass_ctx* c, const float* waveforms, int B, int L, const int* mix_num, const float* comp_db, int max_comp,
+                     const float* noise_db, float* mixture, float* segment, double* scratch, void* stream) {
+    if (!c || !waveforms || !mix_num || !comp_db || !noise_db || !mixture || !segment || !scratch || B <= 0 || L <= 0)
+        return fail(c, LASS_ERR_ARG, "lass_segment_mix: bad argument");
+    if (max_comp < 1 || max_comp > 7) return fail(c, LASS_ERR_ARG, "lass_segment_mix: max_comp (max_mix_num - 1) must be 1 ... 7");
+    if (mixture == waveforms || segment == waveforms || mixture == segment)
+        return fail(c, LASS_ERR_ARG, "lass_segment_mix: waveforms, mixture and segment must be three different buffers");
+    if (int r = use_device(c)) return r;
+    HIP_TRY(c, lass_launch_segment_mix(waveforms, B, L, mix_num, comp_db, max_comp, noise_db, mixture, segment, scratch,
+                                       (hipStream_t)stream));
+    return 0;
+}
+
 // Precomputed analysis of the mixtures (the reference's multi-STFT wrapper reads these from input_dict,
 // resunet_with_multistft.py:233-241): magnitude per branch, cos / sin of the mask branch, each (B, T, nbins).
 struct Components {

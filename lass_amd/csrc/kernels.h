@@ -183,6 +183,11 @@ hipError_t lass_launch_sdr(const float* ref, const float* est, int B, int L, dou
 // scaled by 0.9/max (dcase_evaluator.py:77-89).  source is updated in place; ws: 4*B doubles of scratch.
 hipError_t lass_launch_mix_at_snr(float* source, const float* noise, const float* snr_db, float* mixture, int B, int L,
                                   double* ws, hipStream_t stream);
+// SegmentMixer.__call__ (data/waveform_mixers.py:19-62) with the random draws passed in: clip n + its mix_num[n] - 1 successors
+// (energy-matched, comp_db[n][i] dB each), the noise sum energy-matched again (+ noise_db[n] dB), declipped to a 0.9 peak.
+// ws: 4*B doubles of scratch; max_comp = columns of comp_db (1 ... 7).
+hipError_t lass_launch_segment_mix(const float* waveforms, int B, int L, const int* mix_num, const float* comp_db, int max_comp,
+                                   const float* noise_db, float* mixture, float* segment, double* ws, hipStream_t stream);
 // dst[ci][tap][co] = src[co][ci][tap]
 hipError_t lass_launch_relayout_conv(const float* src, int Cout, int Cin, int taps, float* dst, hipStream_t stream);
 // scale[c] = g/sqrt(var+eps); base[c] = beta - mean*scale

@@ -233,6 +233,94 @@ __global__ __launch_bounds__(256) void mix_declip_kernel(float* __restrict__ src
     }
 }
 
+// ---- SegmentMixer on the device (data/waveform_mixers.py:19-92; SURVEY section 8 row f4, mixer half) --------------------
+// Clip n of a batch is mixed with its mix_num[n] - 1 successors (indices wrap): each is brought to the energy of clip n
+// (ratio = clamp(sqrt(E_next / max(E_n, 1e-10)), 0.02, 50), next / ratio) and given an integer-dB gain; the summed noise
+// gets the same treatment once more (`dynamic_loudnorm`, :85-92), mixture = segment + noise, and a mixture above 1 is
+// brought to a 0.9 peak together with its segment (:49-53).  The random integers (mix_num, the dB draws) are INPUTS, so a
+// restatement with the same draws is an oracle.  ws[n] = {sum x_n^2, sum noise_n^2, max |mixture_n| (float bits), -}.
+__device__ __forceinline__ float seg_ratio(double e_audio, double e_ref, int L) {
+    const float ea = (float)(e_audio / L);                      // get_energy = mean(x^2)   (:71-72)
+    const float er = fmaxf((float)(e_ref / L), 1e-10f);         // max(get_energy(segment2), 1e-10)   (:78)
+    return fminf(fmaxf(sqrtf(ea / er), 0.02f), 50.f);           // clamp(ratio, 0.02, 50)   (:79-80)
+}
+__device__ __forceinline__ float db_gain(float db) { return (float)pow(10.0, (double)db / 20.0); }  // np.power(10.0, d / 20.0)
+
+__global__ __launch_bounds__(256) void seg_energy_kernel(const float* __restrict__ x, int L, double* __restrict__ ws) {
+    __shared__ double red[4];
+    const int b = blockIdx.y;
+    double s0 = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < L; i += gridDim.x * 256) {
+        const double v = x[(size_t)b * L + i];
+        s0 += v * v;
+    }
+    s0 = wave_sum_d(s0);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s0;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&ws[(size_t)b * 4], red[0] + red[1] + red[2] + red[3]);
+}
+
+constexpr int SEG_MAXC = 7;  // components beside the primary segment (max_mix_num <= 8)
+
+// STAGE 0: ws[n][1] = sum noise_n^2.  STAGE 1: mixture = segment + loudnorm(noise), segment copy, ws[n][2] = max |mixture|.
+template <int STAGE>
+__global__ __launch_bounds__(256) void seg_mix_kernel(const float* __restrict__ x, int B, int L, const int* __restrict__ mix_num,
+                                                      const float* __restrict__ comp_db, int max_comp,
+                                                      const float* __restrict__ noise_db, double* __restrict__ ws,
+                                                      float* __restrict__ mixture, float* __restrict__ segment) {
+    __shared__ double red[4];
+    __shared__ float redf[4];
+    const int n = blockIdx.y;
+    int nc = mix_num[n] - 1;
+    nc = nc < 0 ? 0 : (nc > max_comp ? max_comp : nc);
+    const float* src[SEG_MAXC];
+    float ratio[SEG_MAXC], gain[SEG_MAXC];
+#pragma unroll
+    for (int i = 0; i < SEG_MAXC; ++i) {
+        const int o = (n + i + 1) % B;
+        src[i] = x + (size_t)o * L;
+        ratio[i] = i < nc ? seg_ratio(ws[(size_t)o * 4], ws[(size_t)n * 4], L) : 1.f;
+        gain[i] = i < nc ? db_gain(comp_db[(size_t)n * max_comp + i]) : 0.f;
+    }
+    float r2 = 1.f, g2 = 0.f;
+    if (STAGE == 1) {
+        r2 = seg_ratio(ws[(size_t)n * 4 + 1], ws[(size_t)n * 4], L);
+        g2 = db_gain(noise_db[n]);
+    }
+    double s0 = 0;
+    float mx = 0.f;
+    for (int s = blockIdx.x * 256 + threadIdx.x; s < L; s += gridDim.x * 256) {
+        float noise = 0.f;  // noise = zeros; noise += gain * (next / ratio), in component order   (:31-41)
+#pragma unroll
+        for (int i = 0; i < SEG_MAXC; ++i)
+            if (i < nc) noise += gain[i] * (src[i][s] / ratio[i]);
+        if (STAGE == 0) {
+            s0 += (double)noise * (double)noise;
+        } else {
+            const float seg = x[(size_t)n * L + s];
+            const float m = seg + g2 * (noise / r2);
+            mixture[(size_t)n * L + s] = m;
+            segment[(size_t)n * L + s] = seg;
+            mx = fmaxf(mx, fabsf(m));
+        }
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (STAGE == 0) {
+        s0 = wave_sum_d(s0);
+        if (lane == 0) red[wv] = s0;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(&ws[(size_t)n * 4 + 1], red[0] + red[1] + red[2] + red[3]);
+    } else {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        if (lane == 0) redf[wv] = mx;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            atomicMax(reinterpret_cast<unsigned int*>(&ws[(size_t)n * 4 + 2]),
+                      __float_as_uint(fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]))));
+    }
+}
+
 __global__ __launch_bounds__(256) void relayout_conv_kernel(const float* __restrict__ src, int Cout, int Cin, int taps,
                                                             float* __restrict__ dst) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;  // index into dst [ci][tap][co]
@@ -348,5 +436,21 @@ hipError_t lass_launch_mix_at_snr(float* source, const float* noise, const float
     hipLaunchKernelGGL(mix_power_kernel, dim3(nb, B), dim3(256), 0, stream, source, noise, L, ws);
     hipLaunchKernelGGL(mix_apply_kernel, dim3(nb, B), dim3(256), 0, stream, source, noise, snr_db, L, ws, mixture);
     hipLaunchKernelGGL(mix_declip_kernel, dim3(nb, B), dim3(256), 0, stream, source, mixture, L, ws);
+    return hipGetLastError();
+}
+
+hipError_t lass_launch_segment_mix(const float* waveforms, int B, int L, const int* mix_num, const float* comp_db, int max_comp,
+                                   const float* noise_db, float* mixture, float* segment, double* ws, hipStream_t stream) {
+    if (B <= 0 || L <= 0 || max_comp < 1 || max_comp > SEG_MAXC) return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(ws, 0, sizeof(double) * 4 * B, stream);
+    if (e != hipSuccess) return e;
+    int nb = (L + 256 * 16 - 1) / (256 * 16);
+    if (nb > 64) nb = 64;
+    hipLaunchKernelGGL(seg_energy_kernel, dim3(nb, B), dim3(256), 0, stream, waveforms, L, ws);
+    hipLaunchKernelGGL(seg_mix_kernel<0>, dim3(nb, B), dim3(256), 0, stream, waveforms, B, L, mix_num, comp_db, max_comp, noise_db,
+                       ws, mixture, segment);
+    hipLaunchKernelGGL(seg_mix_kernel<1>, dim3(nb, B), dim3(256), 0, stream, waveforms, B, L, mix_num, comp_db, max_comp, noise_db,
+                       ws, mixture, segment);
+    hipLaunchKernelGGL(mix_declip_kernel, dim3(nb, B), dim3(256), 0, stream, segment, mixture, L, ws);
     return hipGetLastError();
 }

@@ -121,13 +121,25 @@ __global__ __launch_bounds__(256) void multi_stft_kernel(const float* __restrict
     }
 }
 
+#ifdef LASS_STFT_DBG
+// Diagnostic build only (tools/stft_hazard_probe.py): every radix-4 pass of the forward transform of
+// stft2_kernel records, per workgroup, [pass][kind][1024] float2 with kind 0 = the four points as READ from LDS, kind 1 = the
+// three twiddles as READ from the LDS table (slot 0 unused), kind 2 = the four results as COMPUTED, in front of their LDS
+// stores.  A wrong launch then says whether its first wrong value was read (LDS path) or computed (vector ALU).
+__device__ float2* g_stft_dbg = nullptr;
+#define STFT_DBG_REC(kind, slot, val) \
+    if (dbg) dbg[(pass * 3 + (kind)) * N + i + (slot) * (N / 4)] = (val)
+#else
+#define STFT_DBG_REC(kind, slot, val)
+#endif
+
 // ---- generic pair-packed transforms (n_fft in {1024, 2048}, window length <= n_fft) ---------------------------------
 // A real frame needs only half a complex transform: two frames ride in one complex FFT (frame a in the real part, frame b
 // in the imaginary part) and are separated by the Hermitian symmetry of their spectra:
 //     Z = FFT(xa + i xb):   Xa[k] = (Z[k] + conj(Z[N-k])) / 2,   Xb[k] = (Z[k] - conj(Z[N-k])) / (2i)
 // and the other way round for the inverse.  Twiddles and the periodic Hann window come from the 2048-entry table.
 template <int N, bool INV>
-__device__ __forceinline__ float2* fft_c(float2* a, float2* b, const float2* tw2k, int tid) {
+__device__ __forceinline__ float2* fft_c(float2* a, float2* b, const float2* tw2k, int tid, float2* dbg = nullptr) {
     constexpr int LOG2 = N == 1024 ? 10 : 11;
     constexpr int NP4 = LOG2 / 2;
     constexpr int TWS = 2048 / N;
@@ -142,18 +154,23 @@ __device__ __forceinline__ float2* fft_c(float2* a, float2* b, const float2* tw2
             const int j = ((i - k) << 2) + k;
             const int ts = (N / 4 / p) * TWS;
             float2 u0 = src[i], u1 = src[i + N / 4], u2 = src[i + N / 2], u3 = src[i + 3 * N / 4];
+            STFT_DBG_REC(0, 0, u0); STFT_DBG_REC(0, 1, u1); STFT_DBG_REC(0, 2, u2); STFT_DBG_REC(0, 3, u3);
             if (pass > 0) {
-                u1 = ctw<INV>(u1, tw2k[k * ts]);
-                u2 = ctw<INV>(u2, tw2k[2 * k * ts]);
-                u3 = ctw<INV>(u3, tw2k[3 * k * ts]);
+                const float2 w1 = tw2k[k * ts], w2 = tw2k[2 * k * ts], w3 = tw2k[3 * k * ts];
+                STFT_DBG_REC(1, 1, w1); STFT_DBG_REC(1, 2, w2); STFT_DBG_REC(1, 3, w3);
+                u1 = ctw<INV>(u1, w1);
+                u2 = ctw<INV>(u2, w2);
+                u3 = ctw<INV>(u3, w3);
             }
             const float2 a0 = cadd(u0, u2), a1 = csub(u0, u2), a2 = cadd(u1, u3);
             float2 a3 = csub(u1, u3);
             a3 = INV ? make_float2(-a3.y, a3.x) : make_float2(a3.y, -a3.x);  // * (+i) inverse, * (-i) forward
-            dst[j] = cadd(a0, a2);
-            dst[j + p] = cadd(a1, a3);
-            dst[j + 2 * p] = csub(a0, a2);
-            dst[j + 3 * p] = csub(a1, a3);
+            const float2 r0 = cadd(a0, a2), r1 = cadd(a1, a3), r2 = csub(a0, a2), r3 = csub(a1, a3);
+            STFT_DBG_REC(2, 0, r0); STFT_DBG_REC(2, 1, r1); STFT_DBG_REC(2, 2, r2); STFT_DBG_REC(2, 3, r3);
+            dst[j] = r0;
+            dst[j + p] = r1;
+            dst[j + 2 * p] = r2;
+            dst[j + 3 * p] = r3;
         }
         __syncthreads();
         float2* t = src; src = dst; dst = t;
@@ -223,7 +240,12 @@ __global__ __launch_bounds__(256) void stft2_kernel(const float* __restrict__ wa
         A[idx] = v;
     }
     __syncthreads();
+#ifdef LASS_STFT_DBG
+    float2* dbg = g_stft_dbg ? g_stft_dbg + (size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (N == 1024 ? 5 : 5) * 3 * N : nullptr;
+    const float2* Z = fft_c<N, false>(A, Bf, TW, tid, dbg);
+#else
     const float2* Z = fft_c<N, false>(A, Bf, TW, tid);
+#endif
     float *mag = a.mag[z], *cosv = a.cosv[z], *sinv = a.sinv[z], *real = a.real[z], *imag = a.imag[z];
     for (int f = tid; f < NB; f += 256) {
         const float2 z1 = Z[f], z2 = Z[(N - f) & (N - 1)];
@@ -372,3 +394,11 @@ hipError_t lass_launch_istft2(const float* real, const float* imag, int B, int T
         hipLaunchKernelGGL(istft2_kernel<2048>, grid, dim3(256), 0, stream, real, imag, T, L, hop, wlen, tw2k, wav);
     return hipGetLastError();
 }
+
+#ifdef LASS_STFT_DBG
+// diagnostic build: the record buffer of the NEXT stft2_kernel launches on `stream` (nullptr = off)
+extern "C" int lass_dbg_stft_buffer(void* buf, hipStream_t stream) {
+    float2* pbuf = (float2*)buf;
+    return (int)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_stft_dbg), &pbuf, sizeof(pbuf), 0, hipMemcpyHostToDevice, stream);
+}
+#endif

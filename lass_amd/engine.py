@@ -206,18 +206,25 @@ class Engine:
         _lib.check(self.ctx, rc, "lass_encoder_block")
         return y, pool
 
-    def front_end(self, wav: torch.Tensor):
+    def front_end(self, wav: torch.Tensor, out=None):
         """(B,L) -> (mag, cos, sin (B,T,n_fft/2+1), x0): STFT + bn0 + T-pad + F-crop (resunet.py:533-552).
         x0 is (B,Tpad,512) for ResUNet30 and (n_windows,B,Tpad,1024) for the multi-STFT model (mag/cos/sin are then the
-        mask window's)."""
+        mask window's).  `out` = a (mag, cos, sin, x0) tuple of an earlier call to write into (no allocation in this call)."""
         wav = self._dev(wav)
         B, L = wav.shape
         T = arch.frames_for(L)
         nb = self.n_fft // 2 + 1
-        mk = lambda: torch.empty(B, T, nb, dtype=torch.float32, device=self.device)  # noqa: E731
-        mag, cos, sin = mk(), mk(), mk()
         shape = (B, arch.padded_frames(T), nb - 1)
-        x0 = torch.empty((self.n_branches,) + shape if self.multistft else shape, dtype=torch.float32, device=self.device)
+        x0_shape = (self.n_branches,) + shape if self.multistft else shape
+        if out is not None:
+            mag, cos, sin, x0 = (self._dev(t) for t in out)
+            if not (mag.shape == cos.shape == sin.shape == (B, T, nb) and tuple(x0.shape) == tuple(x0_shape)
+                    and all(t.dtype == torch.float32 and t.is_contiguous() for t in (mag, cos, sin, x0))):
+                raise ValueError("front_end: `out` does not match this input's shapes")
+        else:
+            mk = lambda: torch.empty(B, T, nb, dtype=torch.float32, device=self.device)  # noqa: E731
+            mag, cos, sin = mk(), mk(), mk()
+            x0 = torch.empty(x0_shape, dtype=torch.float32, device=self.device)
         rc = self.lib.lass_front_end(self.ctx, _ptr(wav), B, L, _ptr(mag), _ptr(cos), _ptr(sin), _ptr(x0),
                                      _stream(self.device))
         _lib.check(self.ctx, rc, "lass_front_end")
@@ -327,6 +334,23 @@ class Engine:
                                       _ptr(scratch), _stream(self.device))
         _lib.check(self.ctx, rc, "lass_mix_at_snr")
         return mixture
+
+    def segment_mix(self, waveforms: torch.Tensor, mix_num: torch.Tensor, comp_db: torch.Tensor, noise_db: torch.Tensor):
+        """data/waveform_mixers.py:19-62 on the device with the random draws given: waveforms (B,L), mix_num (B) int32,
+        comp_db (B, max_mix_num - 1) f32, noise_db (B) f32 -> (mixture (B,L), segment (B,L))."""
+        waveforms = self._dev(waveforms)
+        B, L = waveforms.shape
+        mix_num = mix_num.to(device=self.device, dtype=torch.int32).contiguous()
+        comp_db = comp_db.to(device=self.device, dtype=torch.float32).contiguous()
+        noise_db = noise_db.to(device=self.device, dtype=torch.float32).contiguous()
+        if mix_num.shape != (B,) or noise_db.shape != (B,) or comp_db.dim() != 2 or comp_db.shape[0] != B:
+            raise ValueError("segment_mix: mix_num (B), comp_db (B, max_mix_num - 1), noise_db (B) expected")
+        mixture, segment = torch.empty_like(waveforms), torch.empty_like(waveforms)
+        scratch = torch.empty(B, 4, dtype=torch.float64, device=self.device)
+        rc = self.lib.lass_segment_mix(self.ctx, _ptr(waveforms), B, L, _ptr(mix_num), _ptr(comp_db), int(comp_db.shape[1]),
+                                       _ptr(noise_db), _ptr(mixture), _ptr(segment), _ptr(scratch), _stream(self.device))
+        _lib.check(self.ctx, rc, "lass_segment_mix")
+        return mixture, segment
 
     def graph_stats(self):
         """(enabled, captures, replays) of the hipGraph replay of lass_separate."""

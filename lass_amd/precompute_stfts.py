@@ -101,6 +101,23 @@ def make_precomputed_items(mixtures: torch.Tensor, segments: torch.Tensor, texts
     return items
 
 
+def mix_and_make_precomputed_items(waveforms: torch.Tensor, texts: Sequence[str], mixer, win_lengths: Sequence[int],
+                                   hop_length: int = 160, window: str = "hann", center: bool = True,
+                                   pad_mode: str = "reflect", n_fft: Optional[int] = None) -> List[Dict[str, Any]]:
+    """The producer stage in front of `make_precomputed_items` (scripts/precompute_stfts.py:352-571 mixes a batch of loaded
+    segments with the SegmentMixer recipe before the STFTs): `mixer` = a lass_amd.waveform_mixers.SegmentMixer; clip n is mixed
+    with its mix_num[n] - 1 successors on the device (`lass_segment_mix`), `mixture_component_texts[n]` lists the captions of the
+    primary segment and of the clips mixed in (the recipe's component texts, :160-166), and the spectra of mixtures and declipped
+    segments follow in the same call chain - nothing leaves the device."""
+    if len(texts) != waveforms.shape[0]:
+        raise ValueError("one text per waveform")
+    B = waveforms.shape[0]
+    mix_num, comp_db, noise_db = mixer.draw(B)
+    mixtures, segments = mixer.mix_with_draws(waveforms, mix_num, comp_db, noise_db)
+    comp_texts = [[texts[n]] + [texts[(n + i) % B] for i in range(1, int(mix_num[n]))] for n in range(B)]
+    return make_precomputed_items(mixtures, segments, texts, comp_texts, win_lengths, hop_length, window, center, pad_mode, n_fft)
+
+
 def _to_cpu(value):
     if isinstance(value, torch.Tensor):
         return value.detach().cpu()
