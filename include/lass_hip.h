@@ -89,7 +89,9 @@ int lass_set_param(lass_ctx* ctx, const char* name, const void* data, const int6
 
 /* Fold BatchNorm (eval mode, eps 1e-5) into per-channel scale/shift tables, concatenate the 32 live FiLM linears into
  * one matrix, re-lay-out conv weights to [cin][tap][cout].  Fails if a required parameter is missing.
- * Must be called again after any lass_set_param. */
+ * Must be called again after any lass_set_param.
+ * LASS_ERR_STATE when this process already holds a live context of the other kind of the pair {bf16 / bf16x3 compute mode,
+ * f32 context routed to wino32.hip by LASS_WINO4 != default}: the two may not run side by side (see lass_separate). */
 int lass_finalize(lass_ctx* ctx, int compute_mode);
 
 /* Bytes of workspace `lass_separate` needs for B clips of L samples.
@@ -107,7 +109,16 @@ int lass_workspace_bytes(const lass_ctx* ctx, int B, int L, size_t* bytes);
  * full-size ones (LASS_SPLIT=0: never; =2: eager launches too, the second half on an internal stream forked from /
  * joined to `stream` by events).  Clips are independent: the results are bit-identical to the unsplit run, and `stream`
  * still orders the whole call.  lass_workspace_bytes already accounts for it; lass_workspace_tensor reports
- * LASS_ERR_STATE for such a batch (its workspace may hold two half-batch layouts). */
+ * LASS_ERR_STATE while the last call of that shape ran split (its workspace holds the part-batch layouts).
+ * CAUTION for callers with kernels of their own (gfx950, measured: DESIGN.md section 5b).  While a bf16-mode lass_separate
+ * (LASS_COMPUTE_BF16 / _BF16X3: workgroups feeding v_mfma_f32_32x32x16_bf16 from LDS) runs on one stream, a kernel on ANOTHER
+ * stream that executes packed-f32 vector instructions (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 - hipcc's SLP vectoriser
+ * forms them from float2-shaped code such as complex butterflies) can return wrong values when it shares a compute unit with
+ * them: the x half of a packed result in lanes 48-63 came out wrong from right operands, about one launch in two of an FFT
+ * kernel, never NaN.  Every kernel of this library is built without packed f32 (-fno-slp-vectorize, audited in the ISA by the
+ * test suite) and lass_finalize refuses the one configuration that would bring its only packed-f32 kernel (wino32.hip, f32
+ * contexts behind LASS_WINO4) beside a bf16 context.  Kernels the CALLER launches concurrently are the caller's to build the
+ * same way (or to keep on the same stream as the bf16 lass_separate); f32-mode contexts are not affected. */
 int lass_separate(lass_ctx* ctx, const float* mixture, const float* condition, float* out, int B, int L,
                   void* workspace, size_t workspace_bytes, void* stream);
 
@@ -200,8 +211,10 @@ int lass_front_end(lass_ctx* ctx, const float* wav, int B, int L, float* mag, fl
  * "mag" "cos" "sin" "x0" "out_real" "out_imag", "encoder_blockN" (the skip, stored in place inside the decoder's concat
  * buffer), "encoder_blockN.pool", "conv_block7a", "decoder_blockN.up" (transposed-conv half of the concat),
  * "decoder_blockN" (N = 6 is consumed by the fused output head and never written).  For parity tests of the fused
- * stages against the reference's own taps.  Returns LASS_ERR_ARG for an unknown name, LASS_ERR_STATE for a batch that
- * lass_separate runs as two half-batches (see there). */
+ * stages against the reference's own taps.  Returns LASS_ERR_ARG for an unknown name, and LASS_ERR_STATE when the LAST
+ * lass_separate of this (B, L) ran as part-batches (the replayed graph of an even batch >= 8, or LASS_SPLIT=2): the workspace
+ * then holds their layouts.  After an eager, unsplit call (the first calls of a key, LASS_GRAPH=0, changing pointers) the taps
+ * of any batch size are readable. */
 int lass_workspace_tensor(const lass_ctx* ctx, int B, int L, const char* name, size_t* offset, int64_t shape[4],
                           int64_t strides[4]);
 

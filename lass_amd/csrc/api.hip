@@ -4,6 +4,7 @@
 // one launch.  torch.cat of the decoder (:258) is virtual: encoder blocks write their skip output straight into the
 // second channel half of the decoder's concat buffer and the transposed conv writes the first half.
 #include <hip/hip_runtime.h>
+#include <atomic>
 
 #include <algorithm>
 #include <cmath>
@@ -49,6 +50,7 @@ struct Site {
 struct ResBlock {  // one ConvBlockRes
     std::string prefix;  // "base.encoder_block1.conv_block1"
     int cin = 0, cout = 0;
+    int width = 0;         // bins of the level the block runs at (fcrop >> level): known at finalize, the frame count is not
     int s1 = -1, s2 = -1;  // site indices
     float *w1 = nullptr, *w2 = nullptr, *wsc = nullptr;  // re-laid-out
     float *u1 = nullptr, *u2 = nullptr, *usc = nullptr;  // Winograd-domain copies (when enabled)
@@ -109,6 +111,8 @@ struct lass_ctx {
     int wino4_mincin = 32;     // 3x3 convs with at least that many input channels (and >= 32-wide images) run as Winograd
                                // F(4x4,3x3) (wino4.hip); LASS_WINO4=<min Cin>, 0 = off (F(2x2,3x3) everywhere)
     bool wino32 = true;        // weights-resident persistent kernel for the 32-cout layers (LASS_WINO32=0: wino.hip everywhere)
+    int live_class = 0;        // what this finalized context counts as in the process-wide packed-f32 guard (0 none, 1 bf16 MFMA
+                               // kernels, 2 routes launches to wino32.hip): see packed_guard_enter
     bool fuse_preconv = true;  // LASS_FUSE_PRECONV=0 materialises pre_conv's output with its own kernel
     bool fuse_pool = true;  // LASS_FUSE_POOL=0 selects the stand-alone pool kernel (A/B + parity of both paths)
     bool fuse_catb = true;  // bf16 mode: decoder concats as blocked bf16 copies (LASS_FUSE_CATB=0: f32 concat)
@@ -135,7 +139,11 @@ struct lass_ctx {
         size_t need = 0;         // workspace bytes the captured plan addresses (re-checked on every replay)
         int seen = 0;            // calls with this key so far
         unsigned long used = 0;  // g_tick of the last call (LRU)
+        bool split = false;      // the captured launch sequence runs part-batches (their layouts are what the workspace holds)
     };
+    // (B, L) -> did the LAST lass_separate of that shape run as part-batches?  lass_workspace_tensor refuses only then: eager
+    // calls (the first calls of a key, LASS_GRAPH=0, changing pointers) leave the whole-batch layout, taps stay readable.
+    std::map<std::pair<int, int>, bool> last_split;
     static constexpr int kGraphSlots = 4;
     GraphEntry g_slots[kGraphSlots];
     unsigned long g_tick = 0;
@@ -240,6 +248,7 @@ void build_arch(lass_ctx* c) {
             c->pre_name[k] = "base.pre_convs." + w;
         }
         rb.cin = rb.cout = kPreCh;
+        rb.width = g.fcrop;
         rb.s1 = add_site(c, film + "->beta1", kPreCh);
         rb.s2 = add_site(c, film + "->beta2", kPreCh);
         c->enc.push_back(rb);
@@ -250,6 +259,7 @@ void build_arch(lass_ctx* c) {
         rb.prefix = std::string("base.") + e.name + ".conv_block1";
         rb.cin = e.cin;
         rb.cout = e.cout;
+        rb.width = g.fcrop >> i;  // encoder i (0-based) runs behind i frequency halvings: 512, 256, ..., 16, 8 bins
         rb.s1 = add_site(c, std::string(e.name) + "->conv_block1->beta1", e.cin);
         rb.s2 = add_site(c, std::string(e.name) + "->conv_block1->beta2", e.cout);
         c->enc.push_back(rb);
@@ -263,6 +273,7 @@ void build_arch(lass_ctx* c) {
         rb.prefix = std::string("base.") + d.name + ".conv_block2";
         rb.cin = c->dec_cat[i];
         rb.cout = d.cout;
+        rb.width = g.fcrop >> e;  // decoder i runs at its skip's level: 16, 32, ..., 512 bins
         rb.s1 = add_site(c, std::string(d.name) + "->conv_block2->beta1", rb.cin);
         rb.s2 = add_site(c, std::string(d.name) + "->conv_block2->beta2", d.cout);
         c->dec.push_back(rb);
@@ -798,8 +809,43 @@ int lass_create_multistft(lass_ctx** out, int device_id, int n_fft, int n_window
     return create_impl(out, device_id, g);
 }
 
+// Process-wide guard for the one kernel file that carries packed-f32 arithmetic (wino32.hip's hand-written float2 transform).
+// On gfx950 a wave executing v_pk_*_f32 beside a workgroup that feeds v_mfma_f32_32x32x16_bf16 from LDS returned wrong values
+// (the x half of a packed result, lanes 48-63, from right operands).  Every other kernel is built without
+// packed f32 (-fno-slp-vectorize + ISA audit); wino32.hip runs only in f32 contexts behind LASS_WINO4 != 32.  Two contexts of one
+// process may launch on two streams, so a context that can route to wino32.hip and a context with bf16 MFMA kernels must not be
+// alive together: the second one to finalize is refused.
+static std::atomic<int> g_live_bf16{0}, g_live_w32{0};
+static void packed_guard_leave(lass_ctx* c) {
+    if (c->live_class == 1) --g_live_bf16;
+    if (c->live_class == 2) --g_live_w32;
+    c->live_class = 0;
+}
+static bool routes_to_wino32(const lass_ctx* c, int compute_mode) {
+    // wino4.hip takes every layer wino32.hip could serve when its threshold is at most the 32 channels of those layers
+    return compute_mode == LASS_COMPUTE_F32 && c->wino && c->wino32 && (c->wino4_mincin <= 0 || c->wino4_mincin > kPreCh);
+}
+static int packed_guard_enter(lass_ctx* c, int compute_mode) {
+    packed_guard_leave(c);
+    if (compute_mode != LASS_COMPUTE_F32) {
+        if (g_live_w32.load() > 0)
+            return fail(c, LASS_ERR_STATE, "lass_finalize: a context of this process routes launches to wino32.hip (LASS_WINO4), whose packed-f32 "
+                                           "arithmetic is unsafe beside bf16 MFMA kernels on gfx950 - destroy it first, or leave LASS_WINO4 at its default");
+        ++g_live_bf16;
+        c->live_class = 1;
+    } else if (routes_to_wino32(c, compute_mode)) {
+        if (g_live_bf16.load() > 0)
+            return fail(c, LASS_ERR_STATE, "lass_finalize: LASS_WINO4 routes this f32 context to wino32.hip, whose packed-f32 arithmetic is unsafe "
+                                           "beside the bf16 MFMA kernels of another live context on gfx950 - destroy that context first, or set LASS_WINO32=0");
+        ++g_live_w32;
+        c->live_class = 2;
+    }
+    return 0;
+}
+
 int lass_destroy(lass_ctx* c) {
     if (!c) return LASS_ERR_ARG;
+    packed_guard_leave(c);
     (void)hipSetDevice(c->device);
     free_owned(c);
     for (auto& kv : c->raw) (void)hipFree(kv.second.d);
@@ -850,6 +896,8 @@ int lass_finalize(lass_ctx* c, int compute_mode) {
     if (!c) return LASS_ERR_ARG;
     if (compute_mode != LASS_COMPUTE_F32 && compute_mode != LASS_COMPUTE_BF16 && compute_mode != LASS_COMPUTE_BF16X3)
         return fail(c, LASS_ERR_ARG, "unsupported compute mode");
+    if (int r = packed_guard_enter(c, compute_mode)) return r;
+    c->last_split.clear();
     c->compute_mode = compute_mode;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipDeviceSynchronize());  // replays of graphs that hold the old derived buffers have drained
@@ -922,13 +970,15 @@ int lass_finalize(lass_ctx* c, int compute_mode) {
                 return LASS_ERR_HIP;
             HIP_TRY(c, lass_launch_wino_weights(w1, rb.cout, rb.cin, rb.u1, st));
             HIP_TRY(c, lass_launch_wino_weights(w2, rb.cout, rb.cout, rb.u2, st));
-            if (c->wino4_mincin > 0 && rb.cin >= c->wino4_mincin && rb.cin % 8 == 0 && rb.cout % 32 == 0) {
+            // (F(4x4,3x3) tiles need 32-bin multiples - lass_wino4_supported - so the 16-/8-bin levels get no images: 106 MB saved)
+            const bool w4_level = rb.width % 32 == 0;
+            if (w4_level && c->wino4_mincin > 0 && rb.cin >= c->wino4_mincin && rb.cin % 8 == 0 && rb.cout % 32 == 0) {
                 if (dev_alloc(c, &rb.u1f, (size_t)36 * rb.cout * rb.cin)) return LASS_ERR_HIP;
                 HIP_TRY(c, lass_launch_wino4_weights(w1, rb.cout, rb.cin, rb.u1f, st));
             }
             // conv2: the blocks with a 1x1 shortcut, and encoder_block1 (32 -> 32, residual = pre_conv(x0)); the identity blocks
             // at the bottom of the U-Net (16 / 8 bins) stay with wino.hip
-            if (c->wino4_mincin > 0 && rb.cout >= c->wino4_mincin && (rb.cin != rb.cout || rb.cout == kPreCh) && rb.cout % 32 == 0 &&
+            if (w4_level && c->wino4_mincin > 0 && rb.cout >= c->wino4_mincin && (rb.cin != rb.cout || rb.cout == kPreCh) && rb.cout % 32 == 0 &&
                 rb.cin % 8 == 0) {
                 if (dev_alloc(c, &rb.u2f, (size_t)36 * rb.cout * rb.cout)) return LASS_ERR_HIP;
                 HIP_TRY(c, lass_launch_wino4_weights(w2, rb.cout, rb.cout, rb.u2f, st));
@@ -1181,8 +1231,9 @@ int lass_front_end(lass_ctx* c, const float* wav, int B, int L, float* mag, floa
 int lass_workspace_tensor(const lass_ctx* c, int B, int L, const char* name_c, size_t* offset, int64_t shape[4],
                           int64_t strides[4]) {
     if (!c || !name_c || !offset || !shape || !strides) return LASS_ERR_ARG;
-    // a batch that runs as two half-batches (B >= 8, LASS_SPLIT) keeps two half-batch layouts in its workspace, not this one
-    if (split_halves(c, B)) return LASS_ERR_STATE;
+    // a batch whose LAST separation ran as part-batches (B >= 8, LASS_SPLIT: the replayed graph by default) holds their layouts
+    // in its workspace, not this one; after an eager, unsplit call - or before any call - the whole-batch layout is what is there
+    if (auto it = c->last_split.find({B, L}); it != c->last_split.end() && it->second) return LASS_ERR_STATE;
     Plan pl;
     if (make_plan(c, B, L, &pl)) return LASS_ERR_ARG;
     const Geometry& g = c->g;
@@ -1464,8 +1515,11 @@ static int separate_any(lass_ctx* c, const float* mixture, const float* conditio
     Plan ph;
     const int P = c->finalized ? split_parts(c, B) : 1;
     if (P < 2 || !mixture || !condition || !out || !workspace || (!capturing && c->split_batch < 2) || make_plan(c, B / P, L, &ph) ||
-        P * ((ph.total + 255) / 256 * 256) > workspace_bytes)
+        P * ((ph.total + 255) / 256 * 256) > workspace_bytes) {
+        c->last_split[{B, L}] = false;
         return separate_impl(c, mixture, nullptr, condition, out, B, L, workspace, workspace_bytes, stream, "lass_separate");
+    }
+    c->last_split[{B, L}] = true;
     HIP_TRY(c, hipSetDevice(c->device));
     if (!c->ev_fork) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     for (int i = 0; i < P - 1; ++i)
@@ -1531,6 +1585,7 @@ int lass_separate(lass_ctx* c, const float* mixture, const float* condition, flo
             HIP_TRY(c, hipSetDevice(c->device));
             HIP_TRY(c, hipGraphLaunch(slot->exec, (hipStream_t)stream));
             ++c->g_replays;
+            c->last_split[{B, L}] = slot->split;
             return 0;
         }
         if (slot->seen >= 3) {  // worth a capture
@@ -1559,6 +1614,7 @@ int lass_separate(lass_ctx* c, const float* mixture, const float* condition, flo
                 const hipError_t e = hipStreamEndCapture(c->g_stream, &graph);  // always ends the capture, also after a failure
                 if (r == 0 && e == hipSuccess && graph && hipGraphInstantiate(&slot->exec, graph, nullptr, nullptr, 0) == hipSuccess)
                     ok = true;
+                if (auto it = c->last_split.find({B, L}); it != c->last_split.end()) slot->split = it->second;
                 else
                     slot->exec = nullptr;
                 if (graph) (void)hipGraphDestroy(graph);

@@ -141,6 +141,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino4_kernel(ConvArgs p) {
     const bool edge = left || right || rowok != 0x3fu;  // this item's patch reaches into the zero padding
     float4 pc[6];
     float pl[6], pr[6], ps = 1.f, ph = 0.f;
+    const unsigned tvo = (unsigned)c8 * 4u;  // this item's entry of a per-channel table, within the chunk
+    const auto tab_rsrc = [&](const float* t, int n) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(t), 0, n * 4, 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t sc_rsrc = tab_rsrc(PRO ? sc : p.in, p.Cin), sh_rsrc = tab_rsrc(PRO ? sh : p.in, p.Cin);
+    const __amdgpu_buffer_rsrc_t pw_rsrc = tab_rsrc(PRE ? p.pre_w : p.in, 32), pb_rsrc = tab_rsrc(PRE ? p.pre_b : p.in, 32);
     auto pload = [&](int ch) {
         const unsigned soff = PRE ? 0u : (unsigned)(ch * KC * HW) * 4u;
         if (!PRE || ch == 0)  // PRE: every channel is an affine function of the one x0 patch, loaded once
@@ -150,12 +156,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino4_kernel(ConvArgs p) {
             pl[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, (int)vo_l[i], (int)soff, 0));
             pr[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, (int)vo_r[i], (int)soff, 0));
         }
+        // The table reads are buffer loads as well (one vector-memory instruction each, by construction): wait_vmcnt<NLOAD> below
+        // counts them, and a plain C++ load could be merged, hoisted or scalarised by the compiler behind the count's back.
+        const unsigned toff = (unsigned)(ch * KC) * 4u;
         if (PRO) {
-            ps = sc[ch * KC + c8];
-            ph = sh[ch * KC + c8];
+            ps = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(sc_rsrc, (int)tvo, (int)toff, 0));
+            ph = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(sh_rsrc, (int)tvo, (int)toff, 0));
         }
         if (PRE) {  // leaky(bn(pre_w x0 + pre_b) + beta) = leaky(x0 * (pre_w s) + (pre_b s + h))
-            const float pw = p.pre_w[ch * KC + c8], pb = p.pre_b[ch * KC + c8];
+            const float pw = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pw_rsrc, (int)tvo, (int)toff, 0));
+            const float pb = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pb_rsrc, (int)tvo, (int)toff, 0));
             ph = fmaf(pb, ps, ph);
             ps = pw * ps;
         }

@@ -281,8 +281,9 @@ class Engine:
         shape, strides = (c_int64 * 4)(), (c_int64 * 4)()
         rc = self.lib.lass_workspace_tensor(self.ctx, B, L, name.encode(), byref(off), shape, strides)
         if rc == -3:  # LASS_ERR_STATE
-            raise _lib.LassError(f"lass_workspace_tensor: a batch of {B} clips runs as two half-batches in this mode (the workspace "
-                                 "holds two half-batch layouts): use LASS_SPLIT=0 or a batch below 8 to tap intermediates")
+            raise _lib.LassError(f"lass_workspace_tensor: the last separation of {B} clips ran as two half-batches (the workspace "
+                                 "holds two half-batch layouts): tap after an eager call (set_graph_replay(False)), with "
+                                 "LASS_SPLIT=0, or with a batch below 8")
         if rc < 0:
             raise _lib.LassError(f"lass_workspace_tensor: unknown tensor '{name}' or bad shape")
         ws = self._ws_buf if self._ws_last == (B, L) else None

@@ -316,6 +316,43 @@ def test_c_abi_error_paths(eng, synthetic_sd):
     assert torch.isfinite(eng.separate(mix, cond)).all()
 
 
+def test_packed_f32_guard_between_contexts(synthetic_sd, monkeypatch):
+    """wino32.hip is the one kernel file with packed-f32 arithmetic (hand-written float2); it serves f32 contexts
+    behind LASS_WINO4 != 32 only.  Two contexts of a process may launch on two streams, so `lass_finalize` refuses - in code - to
+    have a bf16-MFMA context and a wino32-routed context alive together, whichever comes second."""
+    import gc
+    from lass_amd._lib import LassError
+    from lass_amd.resunet import ResUNet30
+
+    def make(mode):
+        m = ResUNet30(1, 1, 512)
+        m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synthetic_sd.items()})
+        m = m.to(DEV).eval().set_compute_dtype(mode)
+        m.engine   # lass_create (reads the switches) + lass_finalize happen here
+        return m
+
+    gc.collect()
+    bf = make("bf16")
+    monkeypatch.setenv("LASS_WINO4", "0")
+    with pytest.raises(LassError, match="wino32"):
+        make("f32")
+    monkeypatch.setenv("LASS_WINO32", "0")      # F(2x2,3x3) through wino.hip (no packed f32): allowed beside bf16
+    ok = make("f32")
+    del ok
+    monkeypatch.delenv("LASS_WINO32")
+    del bf
+    gc.collect()
+    w32 = make("f32")                              # alone: allowed
+    monkeypatch.delenv("LASS_WINO4")
+    with pytest.raises(LassError, match="wino32"):
+        make("bf16")
+    with pytest.raises(LassError, match="wino32"):
+        make("bf16x3")
+    del w32
+    gc.collect()
+    make("bf16")                                   # and allowed again once the wino32-routed context is gone
+
+
 def test_random_shapes_against_oracle(model, oracle_sd):
     """Seeded random (batch, length) pairs - lengths that are no multiple of the hop, frame counts that leave odd heights
     down the U-Net, batch sizes that do not fill a tile - against the CPU oracle."""
@@ -717,6 +754,22 @@ def test_half_batch_overlap_is_bit_identical(synthetic_sd, monkeypatch, mode):
     assert captures >= 1 and replays >= 1, (captures, replays)   # the two-stream form captures as one graph with two branches
     with pytest.raises(Exception, match="half-batches"):   # the workspace holds two half-batch layouts, not the B = 16 one
         engines["1"].workspace_tensor("out_real", B, L)
+    # ... and only then: the default schedule (LASS_SPLIT=1) splits the REPLAYED graph only, so after eager calls of the same
+    # batch the whole-batch layout is in the workspace and its taps are readable
+    if mode == "f32":
+        m = ResUNet30(1, 1, 512)
+        m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synthetic_sd.items()})
+        e1 = m.to(DEV).eval().engine
+        e1.set_graph_replay(False)
+        o1 = e1.separate(x, cond)
+        tap = e1.workspace_tensor("out_real", B, L)
+        assert tap.shape[0] == B and torch.isfinite(tap).all() and float(tap.abs().max()) > 0
+        assert torch.equal(o1, ref)
+        e1.set_graph_replay(True)
+        for _ in range(4):                                   # third identical call captures, fourth replays: split from then on
+            e1.separate(x, cond, out=out)
+        with pytest.raises(Exception, match="half-batches"):
+            e1.workspace_tensor("out_real", B, L)
 
 
 @pytest.mark.parametrize("B,L,parts", [(8, 25600, "2"), (10, 40000, "2"), (16, 16000, "4"), (9, 25600, "2")])
