@@ -513,7 +513,26 @@ def main():
                             f"-> SDR/SDRi/SI-SDR means), batch {B}, ragged tail of {n_ev % B}; 1 warm-up call, median of 5 (the decode threads share the box's CPUs: single calls scatter by 20 %)",
                 "clips_s": n_ev / dt_ev, "calls_s": [n_ev / d for d in dts], "separator_clips_s": sep_rate,
                 "evaluator_over_separator": n_ev / dt_ev / sep_rate,
+                "data_path": ev.last_path, "resident_batches": ev.resident_batches, "generic_batches": ev.generic_batches,
                 "mean_sisdr_sdri_sdr": [float(v) for v in outv]}
+            if "bf16" in modes:
+                # the same call with the bf16-MFMA separator (configs[2]): at ~3 300 clips/s the loop's own work - 20 MB of H2D,
+                # the mixing and statistics kernels, 32 file reads per batch - is a visible share; reported, not hidden
+                model.set_compute_dtype("bf16")
+                ev(plm)
+                dtb = []
+                for _ in range(5):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    outb = ev(plm)
+                    torch.cuda.synchronize()
+                    dtb.append(time.perf_counter() - t0)
+                dt_b = sorted(dtb)[2]
+                modes["evaluator_e2e_bf16"] = {
+                    "clips_s": n_ev / dt_b, "calls_s": [n_ev / d for d in dtb], "separator_clips_s": modes["bf16"]["clips_s"],
+                    "evaluator_over_separator": n_ev / dt_b / modes["bf16"]["clips_s"], "data_path": ev.last_path,
+                    "mean_sisdr_sdri_sdr": [float(v) for v in outb]}
+                model.set_compute_dtype(args.dtype)
         finally:
             shutil.rmtree(tmp, ignore_errors=True)
 

@@ -323,14 +323,18 @@ class Engine:
         _lib.check(self.ctx, rc, "lass_sdr_stats")
         return stats
 
-    def mix_at_snr(self, source: torch.Tensor, noise: torch.Tensor, snr_db: torch.Tensor):
+    def mix_at_snr(self, source: torch.Tensor, noise: torch.Tensor, snr_db: torch.Tensor, out: Optional[torch.Tensor] = None,
+                   scratch: Optional[torch.Tensor] = None):
         """dcase_evaluator.py:77-89 on the device.  source (B,L) is scaled IN PLACE when the mixture needs declipping;
-        returns the mixture (B,L)."""
+        returns the mixture (B,L) (`out` / `scratch` (B,4) f64: caller-kept buffers, nothing allocated here)."""
         source, noise, snr_db = self._dev(source), self._dev(noise), self._dev(snr_db)
         B, L = source.shape
         assert noise.shape == source.shape and snr_db.shape == (B,)
-        mixture = torch.empty_like(source)
-        scratch = torch.empty(B, 4, dtype=torch.float64, device=self.device)
+        mixture = torch.empty_like(source) if out is None else self._dev(out)
+        assert mixture.shape == source.shape and mixture.is_contiguous() and mixture.dtype == torch.float32
+        if scratch is None:
+            scratch = torch.empty(B, 4, dtype=torch.float64, device=self.device)
+        assert scratch.dtype == torch.float64 and scratch.numel() >= 4 * B and scratch.is_contiguous()
         rc = self.lib.lass_mix_at_snr(self.ctx, _ptr(source), _ptr(noise), _ptr(snr_db), _ptr(mixture), B, L,
                                       _ptr(scratch), _stream(self.device))
         _lib.check(self.ctx, rc, "lass_mix_at_snr")

@@ -10,6 +10,13 @@ definitions and the same printed line.  Differences are in execution only:
     through pinned double buffers on a copy stream (`_Stager`: the host never waits on the GPU inside the loop), and
     caption embeddings are cached per caption (captions repeat; the query encoder is called once per distinct caption);
     `device_mixing=False` restores the reference's host-side numpy mixing (used by the parity tests as the yardstick);
+  * (round 5) the RESIDENT path, taken when the separator offers `separate_into` (lass_amd.ResUNet30 does) and mixing is on
+    the device: two persistent batch slots - pinned host rows the decode threads fill DIRECTLY (`read_wav_into`: a float32
+    file goes file -> pinned memory in one `readinto`), and one set of device tensors (source, noise, SNR, mixture, condition,
+    output) each - so that `lass_separate` sees recurring pointers: the full batches replay its captured hipGraph with the two
+    overlapping half-batches (include/lass_hip.h) instead of launching ~40 kernels eagerly, and the loop allocates nothing per
+    batch.  Any clip that does not fit a slot row (other length, rate, channels) sends its batch through the generic path
+    below; results are identical either way (`resident=False` forces the generic path);
   * under torch.distributed the clip list is block-sharded over ranks and the per-clip metric rows are all-gathered
     once at the end (RCCL when the backend is "nccl").
 """
@@ -28,7 +35,7 @@ from . import dist as ldist
 from .engine import get_engine
 from .metrics import stats_to_db
 from .utils import load_ss_model, parse_yaml
-from .wavio import read_wav
+from .wavio import read_wav, read_wav_into, wav_frames
 
 
 def _mix_on_host(source: np.ndarray, noise: np.ndarray, snr_db: int):
@@ -82,9 +89,24 @@ class _Stager:
         return outs
 
 
+class _Slot:
+    """One resident batch: pinned host rows for the decode threads and the device tensors lass_separate sees again and again."""
+
+    def __init__(self, B: int, L: int, device):
+        pin = lambda *shape: torch.empty(shape, dtype=torch.float32).pin_memory()  # noqa: E731
+        dev = lambda *shape, dtype=torch.float32: torch.empty(shape, dtype=dtype, device=device)  # noqa: E731
+        self.pin_src, self.pin_noise, self.pin_snr = pin(B, L), pin(B, L), pin(B)
+        self.np_src, self.np_noise, self.np_snr = self.pin_src.numpy(), self.pin_noise.numpy(), self.pin_snr.numpy()
+        self.src, self.noise, self.snr, self.mix, self.out = dev(B, L), dev(B, L), dev(B), dev(B, L), dev(B, L)
+        self.cond = dev(B, 512)
+        self.scratch = dev(B, 4, dtype=torch.float64)
+        self.h2d_done = None      # the copy that last read the pinned rows
+        self.compute_done = None  # the kernels that last read / wrote the device tensors
+
+
 class DCASEEvaluator:
     def __init__(self, sampling_rate=16000, eval_indexes="lass_synthetic_validation.csv", audio_dir="lass_validation",
-                 batch_size: int = 16, device_mixing: bool = True, io_workers: int = 2) -> None:
+                 batch_size: int = 16, device_mixing: bool = True, io_workers: int = 2, resident: bool = True) -> None:
         r"""DCASE T9 LASS evaluator (dcase_evaluator.py:28-47)."""
         self.sampling_rate = sampling_rate
         with open(eval_indexes) as csv_file:
@@ -97,6 +119,10 @@ class DCASEEvaluator:
         self.io_workers = max(1, io_workers)
         self.last_rows = None  # (N,3) per-clip [sdr, sdri, sisdr] of the last call (all ranks)
         self._embed_cache: Dict[str, torch.Tensor] = {}
+        self.resident = resident
+        self._slots = {}       # (B, L, device) -> [two _Slot]: kept across calls, so later calls replay graphs from their first batch
+        self.last_path = None  # "resident" / "generic": which data path the last call took (tests, bench)
+        self.resident_batches = self.generic_batches = 0
 
     def _read_pair(self, eval_data):
         """dcase_evaluator.py:67-74 for one csv row: decode the two clips only -> (source, noise, snr, caption)."""
@@ -133,7 +159,124 @@ class DCASEEvaluator:
         lo, hi = ldist.shard_range(n_total, rank, ws)
         rows: List[np.ndarray] = []
         self._embed_cache.clear()  # embeddings belong to this pl_model's query encoder
+        self.resident_batches = self.generic_batches = 0
+        use_resident = (self.resident and self.device_mixing and hasattr(pl_model.ss_model, "separate_into") and hi > lo)
+        self.last_path = "resident" if use_resident else "generic"
+        if use_resident:
+            rows = self._run_resident(pl_model, eng, device, lo, hi)
+        else:
+            rows = self._run_generic(pl_model, eng, device, self.eval_list[lo:hi])
+        local = np.concatenate(rows, axis=0) if rows else np.zeros((0, 3))
+        allrows = ldist.gather_rows(local, n_total, device)
+        self.last_rows = allrows
+        mean_sdr, mean_sdri, mean_sisdr = (float(np.mean(allrows[:, k])) for k in range(3))
+        return mean_sisdr, mean_sdri, mean_sdr
+
+    @staticmethod
+    def _rows_from_stats(pending_stats) -> List[np.ndarray]:
+        rows = []
+        for st_sep, st_mix, length in pending_stats:
+            sdr, sisdr = stats_to_db(st_sep.cpu().numpy(), length)
+            sdr_no_sep, _ = stats_to_db(st_mix.cpu().numpy(), length)
+            rows.append(np.stack([sdr, sdr - sdr_no_sep, sisdr], axis=1))
+        return rows
+
+    def _run_resident(self, pl_model, eng, device, lo: int, hi: int) -> List[np.ndarray]:
+        """The resident data path (module docstring): clip k of this rank's shard lives in row k % B of slot (k // B) % 2."""
+        B = self.batch_size
+        items = self.eval_list[lo:hi]
+        n = len(items)
+        L = wav_frames(os.path.join(self.audio_dir, f"{items[0][0]}.wav"))
+        if L <= 0:
+            return self._run_generic(pl_model, eng, device, items)
+        key = (B, L, str(device))
+        slots = self._slots.get(key)
+        if slots is None:
+            self._slots.clear()  # one shape at a time: 2 x (2 pinned + 5 device) x B x L floats
+            slots = self._slots[key] = [_Slot(B, L, device), _Slot(B, L, device)]
+        nb = (n + B - 1) // B
+        compute = torch.cuda.current_stream(device)
+        copy_stream = torch.cuda.Stream(device)
+        sr = self.sampling_rate
+
+        def decode(k: int):
+            """-> None when both files went straight into the slot rows, else the generic loader's tuple for this clip."""
+            source, noise, snr, _caption = items[k]
+            slot, r = slots[(k // B) % 2], k % B
+            if (read_wav_into(os.path.join(self.audio_dir, f"{source}.wav"), sr, slot.np_src[r])
+                    and read_wav_into(os.path.join(self.audio_dir, f"{noise}.wav"), sr, slot.np_noise[r])):
+                slot.np_snr[r] = float(int(snr))
+                return None
+            return self._read_pair(items[k])
+
+        pending_stats, rows_out = [], []
+        with torch.no_grad(), ThreadPoolExecutor(max_workers=self.io_workers) as pool:
+            futures = {}
+            submitted = 0  # batches whose decode jobs are out
+
+            def submit_ready(upto: int):
+                nonlocal submitted
+                while submitted < min(nb, upto):
+                    slot = slots[submitted % 2]
+                    if slot.h2d_done is not None:
+                        slot.h2d_done.synchronize()  # the copy of batch `submitted - 2` out of these pinned rows (long done)
+                        slot.h2d_done = None
+                    for k in range(submitted * B, min(n, (submitted + 1) * B)):
+                        futures[k] = pool.submit(decode, k)
+                    submitted += 1
+
+            submit_ready(2)
+            for j in range(nb):
+                k0, k1 = j * B, min(n, (j + 1) * B)
+                res = [futures.pop(k).result() for k in range(k0, k1)]
+                slot, m = slots[j % 2], k1 - k0
+                captions = [items[k][3] for k in range(k0, k1)]
+                if all(r is None for r in res):
+                    self.resident_batches += 1
+                    with torch.cuda.stream(copy_stream):
+                        if slot.compute_done is not None:
+                            copy_stream.wait_event(slot.compute_done)  # batch j - 2 has finished with these device tensors
+                        slot.src[:m].copy_(slot.pin_src[:m], non_blocking=True)
+                        slot.noise[:m].copy_(slot.pin_noise[:m], non_blocking=True)
+                        slot.snr[:m].copy_(slot.pin_snr[:m], non_blocking=True)
+                        slot.h2d_done = torch.cuda.Event()
+                        slot.h2d_done.record(copy_stream)
+                    compute.wait_event(slot.h2d_done)
+                    src, mix, cond, out = slot.src[:m], slot.mix[:m], slot.cond[:m], slot.out[:m]
+                    eng.mix_at_snr(src, slot.noise[:m], slot.snr[:m], out=mix, scratch=slot.scratch)
+                    cond.copy_(self._conditions(pl_model, captions, device))
+                    pl_model.ss_model.separate_into(mix, cond, out)
+                    pending_stats.append((eng.sdr_stats(src, out), eng.sdr_stats(src, mix), L))
+                    slot.compute_done = torch.cuda.Event()
+                    slot.compute_done.record(compute)
+                    # batch j + 2 reuses THIS slot's pinned rows: its decode jobs go out once the copy above has left them
+                    # (submit_ready waits for that copy; the GPU already holds this batch's kernels, so the host can afford to)
+                    submit_ready(j + 3)
+                else:
+                    # some clip of this batch does not fit a slot row: the whole batch takes the generic route (rows that did
+                    # land in the slot are read back out of it), in order, with the statistics kept in sequence
+                    self.generic_batches += 1
+                    group = []
+                    for r_, k in zip(res, range(k0, k1)):
+                        if r_ is None:
+                            r_ = (slot.np_src[k % B].copy(), slot.np_noise[k % B].copy(), int(items[k][2]), items[k][3])
+                        group.append(r_)
+                    submit_ready(j + 3)
+                    rows_out.extend(self._rows_from_stats(pending_stats))
+                    pending_stats = []
+                    rows_out.extend(self._run_generic(pl_model, eng, device, None, decoded=group))
+            rows_out.extend(self._rows_from_stats(pending_stats))
+        return rows_out
+
+    def _run_generic(self, pl_model, eng, device, items, decoded=None) -> List[np.ndarray]:
+        """The generic data path: clips of any length, grouped into batches of consecutive equal-length clips, fresh device
+        tensors per batch (eager launches).  `decoded`: already decoded (source, noise, snr, caption) tuples instead of csv rows."""
+        rows: List[np.ndarray] = []
         loader = self._read_pair if self.device_mixing else self._load_clip
+        if decoded is not None:
+            assert self.device_mixing
+            items, loader = decoded, (lambda t: t)
+        lo, hi = 0, len(items)
         with torch.no_grad(), ThreadPoolExecutor(max_workers=self.io_workers) as pool:
             # sliding window of decode jobs: at most two batches ahead of the one on the GPU
             pending = deque()
@@ -144,7 +287,7 @@ class DCASEEvaluator:
             def refill():
                 nonlocal nxt
                 while nxt < hi and len(pending) < 2 * self.batch_size:
-                    pending.append(pool.submit(loader, self.eval_list[nxt]))
+                    pending.append(pool.submit(loader, items[nxt]))
                     nxt += 1
 
             refill()
@@ -172,15 +315,8 @@ class DCASEEvaluator:
                 # the (B,6) f64 statistics stay on the device: no host synchronisation inside the loop, so decoding /
                 # staging of the next batch overlaps this batch's kernels; they are fetched once after the loop
                 pending_stats.append((eng.sdr_stats(src, sep.contiguous()), eng.sdr_stats(src, mix), src.shape[1]))
-            for st_sep, st_mix, length in pending_stats:
-                sdr, sisdr = stats_to_db(st_sep.cpu().numpy(), length)
-                sdr_no_sep, _ = stats_to_db(st_mix.cpu().numpy(), length)
-                rows.append(np.stack([sdr, sdr - sdr_no_sep, sisdr], axis=1))
-        local = np.concatenate(rows, axis=0) if rows else np.zeros((0, 3))
-        allrows = ldist.gather_rows(local, n_total, device)
-        self.last_rows = allrows
-        mean_sdr, mean_sdri, mean_sisdr = (float(np.mean(allrows[:, k])) for k in range(3))
-        return mean_sisdr, mean_sdri, mean_sdr
+            rows.extend(self._rows_from_stats(pending_stats))
+        return rows
 
 
 def eval(evaluator, checkpoint_path, config_yaml="config/audiosep_base.yaml", device="cuda", query_encoder=None):

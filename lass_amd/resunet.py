@@ -138,6 +138,15 @@ class ResUNet30(nn.Module):
         return eng.separate(mix, cond)[:, None, :]
 
     @torch.no_grad()
+    def separate_into(self, mixture: torch.Tensor, condition: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+        """The same call with caller-kept buffers: mixture (B,L), condition (B,512) -> `out` (B,L), all float32 on the model's
+        device.  A caller that presents the SAME buffers again (the evaluator's resident batches) reaches lass_separate's
+        replayed hipGraph and its two overlapping half-batches; `forward` allocates its output and therefore launches eagerly."""
+        if self.training:
+            raise LassError("lass_amd.ResUNet30 is inference-only (call .eval()); training is out of scope")
+        return self._ensure_engine().separate(mixture, condition, out)
+
+    @torch.no_grad()
     def forward(self, input_dict: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         """resunet.py:640-653."""
         return {"waveform": self._separate(input_dict["mixture"], input_dict["condition"])}

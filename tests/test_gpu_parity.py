@@ -443,6 +443,45 @@ def test_evaluator_matches_oracle(tmp_path, model, oracle_sd, L):
     assert sorted(sum(calls, [])) == sorted({f"synthetic tone cluster {i}" for i in range(4)})  # once per caption
 
 
+def test_evaluator_resident_path_equals_generic_path(tmp_path, model):
+    """dcase_evaluator.py:65-122, round 5: the resident data path (decode threads fill pinned slot rows directly, two persistent
+    device batches, recurring pointers -> lass_separate replays its hipGraph with the two overlapping half-batches) returns
+    per-clip rows equal to the generic path's (fresh tensors per batch, eager launches) to 1e-9 dB; a clip of another length sends
+    only its batch through the generic route; later calls replay graphs from their first batch."""
+    from lass_amd import wavio
+    from lass_amd.audiosep import AudioSep, PrecomputedQueryEncoder
+    from lass_amd.evaluator import DCASEEvaluator
+    n, L, B = 41, 24000, 8      # five full batches + a ragged tail of 1
+    csv_path = synthetic.write_validation_set(str(tmp_path), n_clips=n, length=L)
+    adir = os.path.join(str(tmp_path), "lass_validation")
+    pl_model = AudioSep(ss_model=model, query_encoder=PrecomputedQueryEncoder())
+    gen = DCASEEvaluator(16000, csv_path, adir, batch_size=B, resident=False)
+    res = DCASEEvaluator(16000, csv_path, adir, batch_size=B)
+    g = gen(pl_model)
+    assert gen.last_path == "generic"
+    _, cap0, rep0 = model.engine.graph_stats()
+    for call in range(3):
+        r = res(pl_model)
+        assert res.last_path == "resident" and res.resident_batches == 6 and res.generic_batches == 0
+        # (same kernels on the same data; the f64 statistics are accumulated with atomics, whose order is not fixed: 1e-9 dB)
+        np.testing.assert_allclose(res.last_rows, gen.last_rows, rtol=0, atol=1e-9, err_msg=str(call))
+        assert r == pytest.approx(g, abs=1e-9)
+    _, cap1, rep1 = model.engine.graph_stats()
+    assert cap1 > cap0 and rep1 - rep0 >= 8, (cap0, cap1, rep0, rep1)   # the slots' pointers recur: captured, then replayed
+    # a PCM16 file and a clip of another length in the set: that batch (and only that one) takes the generic route
+    x, _ = wavio.read_wav(os.path.join(adir, "src_0003.wav"), 16000)
+    wavio.write_wav_pcm16(os.path.join(adir, "src_0003.wav"), x, 16000)          # still fits a slot row (decoded in place)
+    y, _ = wavio.read_wav(os.path.join(adir, "src_0010.wav"), 16000)
+    wavio.write_wav_f32(os.path.join(adir, "src_0010.wav"), y[:20000], 16000)
+    z, _ = wavio.read_wav(os.path.join(adir, "noise_0010.wav"), 16000)
+    wavio.write_wav_f32(os.path.join(adir, "noise_0010.wav"), z[:20000], 16000)
+    g2 = gen(pl_model)
+    r2 = res(pl_model)
+    assert res.last_path == "resident" and res.generic_batches == 1 and res.resident_batches == 5
+    np.testing.assert_allclose(res.last_rows, gen.last_rows, rtol=0, atol=1e-9)
+    assert r2 == pytest.approx(g2, abs=1e-9)
+
+
 def test_eval_from_checkpoint_default_config(tmp_path, synthetic_sd, oracle_sd, capsys, monkeypatch):
     """SURVEY §8 a14 / f2 end to end on the GPU: a Lightning-shaped `.ckpt` (`state_dict['ss_model.*']` next to
     `query_encoder.*` keys and the torchlibrosa buffers a reference checkpoint carries, utils.py:387-398) goes through
