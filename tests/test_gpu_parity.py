@@ -353,6 +353,43 @@ def test_packed_f32_guard_between_contexts(synthetic_sd, monkeypatch):
     make("bf16")                                   # and allowed again once the wino32-routed context is gone
 
 
+def test_integration_md_ctypes_stub_runs_verbatim(tmp_path, synthetic_sd, oracle_sd):
+    """INTEGRATION.md section B shows the binding a maintainer adds on the reference side (a ctypes `HipSeparator` around the
+    five C-ABI calls).  The code block is taken out of the document and executed as written - only the library's file name is
+    made absolute - against the oracle: documentation that cannot rot."""
+    import importlib.util
+    import re
+    from lass_amd import _lib
+    from lass_amd.resunet import ResUNet30
+    from oracle import resunet as orr
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    sec_b = text[text.index("## B. Bind the C-ABI directly"):]
+    code = re.search(r"```python\n(.*?)```", sec_b, re.S).group(1)
+    assert "class HipSeparator" in code and 'ctypes.CDLL("liblass_hip.so")' in code
+    code = code.replace('ctypes.CDLL("liblass_hip.so")', f'ctypes.CDLL({_lib.LIB_PATH!r})')
+    path = os.path.join(str(tmp_path), "resunet_hip.py")
+    open(path, "w").write(code)
+    spec = importlib.util.spec_from_file_location("resunet_hip", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    # `m`: a module with the reference's state_dict (keys, shapes, extra torchlibrosa buffers included); weights on the HOST
+    m = ResUNet30(1, 1, 512)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synthetic_sd.items()})
+    sd = dict(m.state_dict())
+    sd["base.stft.conv_real.weight"] = torch.zeros(513, 1, 1024)
+    holder = type("RefModule", (), {"state_dict": lambda self: sd})()
+    hip_sep = mod.HipSeparator(holder, 0)
+    _, mix = synthetic.make_mixtures(2, 20000)
+    cond = torch.from_numpy(synthetic.make_condition(2))
+    out = hip_sep({"mixture": torch.from_numpy(mix)[:, None, :].to(DEV), "condition": cond.to(DEV)})["waveform"]
+    assert out.shape == (2, 1, 20000)
+    ref = orr.forward(oracle_sd, {"mixture": torch.from_numpy(mix)[:, None, :], "condition": cond})["waveform"]
+    assert _rms(out.cpu() - ref) <= 1e-5
+    with pytest.raises(RuntimeError):   # the stub's error path: lass_separate's message comes back through lass_last_error
+        hip_sep({"mixture": torch.zeros(1, 1, 100, device=DEV), "condition": cond[:1].to(DEV)})
+
+
 def test_random_shapes_against_oracle(model, oracle_sd):
     """Seeded random (batch, length) pairs - lengths that are no multiple of the hop, frame counts that leave odd heights
     down the U-Net, batch sizes that do not fill a tile - against the CPU oracle."""
