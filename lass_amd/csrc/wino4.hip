@@ -62,8 +62,14 @@ __device__ __forceinline__ void at6(const float (&m)[6], float (&y)[4]) {
 }
 
 // TC: tile columns of the block (32 tiles = (32 / TC) tile rows x TC tile columns; block = 4 * (32 / TC) rows x 4 * TC columns)
-template <int TC, int FLAGS>
-__global__ __launch_bounds__(NTHREADS, 2) void wino4_kernel(ConvArgs p) {
+// NG: 32-cout groups per workgroup.  NG = 1: 4 waves, 32 couts x 32 tiles, two workgroups per CU (round 4).
+// NG = 2 (round 5): 8 waves, 64 couts x 32 tiles, ONE workgroup per CU (U 72 KiB + V 36 KiB).  The transformed input V of a
+// chunk is shared by 64 couts - every input tile is transformed once per 64 instead of once per 32 output channels.  Waves
+// w and w + 4 sit on one SIMD; the halves {0-3} and {4-7} take turns: chunk c is transformed by half c & 1 (one wave per SIMD
+// in the transform, 256 items as before) while the other half issues the chunk's weight DMA (72 pieces) - then all eight waves
+// run the chunk's 72 MFMAs each.  Per SIMD and chunk: 144 MFMAs beside ONE input transform (NG = 1: beside two).
+template <int TC, int FLAGS, int NG = 1>
+__global__ __launch_bounds__(NTHREADS * NG, 2) void wino4_kernel(ConvArgs p) {
     constexpr bool PRO = (FLAGS & F_PRO) != 0, EPI = (FLAGS & F_EPIACT) != 0, SC = (FLAGS & F_PHASEB) != 0;
     constexpr bool PRE = (FLAGS & F_PRECONV) != 0;   // the input is the 1-channel x0: channel c = pre_w[c] * x0 + pre_b[c] (resunet.py:555)
     constexpr bool RESPRE = (FLAGS & F_RESPRE) != 0; // identity residual = pre_conv(x0), never materialised (encoder_block1.conv2)
@@ -74,19 +80,24 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino4_kernel(ConvArgs p) {
     static_assert(!MASK || SC, "the output head sits behind decoder_block6's conv2 + shortcut");
     constexpr int TR = 32 / TC;
     constexpr int OR_ = 4 * TR, OC = 4 * TC;
-    __shared__ __attribute__((aligned(16))) float lds[U_F + V_F + 64 + (MASK ? 100 : 0)];
+    static_assert(NG == 1 || NG == 2, "one or two 32-cout groups per workgroup");
+    static_assert(NG == 1 || !MASK, "the fused output head is a 32-cout launch");
+    static_assert(NG == 1 || (!PRE && !RESPRE), "encoder_block1's kinds are 32-cout launches");
+    constexpr int NCO = 32 * NG;  // output channels of the workgroup
+    __shared__ __attribute__((aligned(16))) float lds[NG * U_F + V_F + 2 * NCO + (MASK ? 100 : 0)];
     float* lu = lds;
-    float* lv = lds + U_F;
+    float* lv = lds + NG * U_F;
     float* lds_es = lv + V_F;
-    float* lds_eh = lds_es + 32;
-    float* lds_mw = lds_eh + 32;  // MASK: after_conv weight [3][32] + bias [3]
+    float* lds_eh = lds_es + NCO;
+    float* lds_mw = lds_eh + NCO;  // MASK: after_conv weight [3][32] + bias [3]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wco = wave >> 1, wwt = wave & 1;  // cout tile (16 couts) / tile group (16 tiles) of this wave
+    const int wco = wave >> 1, wwt = wave & 1;  // cout tile (16 couts, 0 .. 2 NG - 1) / tile group (16 tiles) of this wave
+    const int half = NG == 2 ? (wave >> 2) : 0;  // NG = 2: which half of the workgroup (waves 0-3 / 4-7: SIMD partners w, w + 4)
     int bx_, by_, b;
     block_coords(p, bx_, by_, b);
-    const int n0 = by_ * 32;
+    const int n0 = by_ * NCO;
     const int tiles_x = p.W / OC;
     const int y0 = (bx_ / tiles_x) * OR_, x0 = (bx_ % tiles_x) * OC;
     const int HW = p.H * p.W;
@@ -94,11 +105,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino4_kernel(ConvArgs p) {
     const float* sc = PRO ? p.pro_scale : nullptr;
     const float* sh = PRO ? p.pro_shift + (size_t)b * p.pro_shift_bs : nullptr;
 
-    if (EPI && tid < 32) {
+    if (EPI && tid < NCO) {
         lds_es[tid] = p.epi_scale[n0 + tid];
         lds_eh[tid] = p.epi_shift[(size_t)b * p.epi_shift_bs + n0 + tid];
     }
-    if (SC && tid < 32) lds_es[tid] = p.bias[n0 + tid];  // (SC and EPI exclude each other: one table)
+    if (SC && tid < NCO) lds_es[tid] = p.bias[n0 + tid];  // (SC and EPI exclude each other: one table)
     if (RESPRE && tid < 32) {                               // residual affine of this block's 32 output channels
         lds_es[tid] = p.pre_w[n0 + tid];
         lds_eh[tid] = p.pre_b[n0 + tid];
@@ -113,7 +124,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino4_kernel(ConvArgs p) {
 
     const int kq = lane >> 4, l15 = lane & 15;
     // fragments: U image [xi][t][kq][l15][k]: this lane's {k-step 0, k-step 1} of cout tile wco; V image [xi][kq][tile ^ swz][k]
-    const float* afrag = lu + wco * 128 + (kq * 16 + l15) * 2;
+    const float* afrag = lu + (wco >> 1) * U_F + (wco & 1) * 128 + (kq * 16 + l15) * 2;  // slab of the 32-cout group, cout tile inside it
     const float* bfrag = lv + (kq * 32 + ((wwt * 16 + l15) ^ ((kq & 1) << 4))) * 2;
     const unsigned slab_pitch = (unsigned)(p.Nw / 32) * (unsigned)(U_F * 4);  // bytes between the slabs of consecutive chunks
     const unsigned slab_n0 = (unsigned)(n0 / 32) * (unsigned)(U_F * 4);
@@ -122,7 +133,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino4_kernel(ConvArgs p) {
     const v4i32 uw = make_rsrc_words(p.w_wino4, (unsigned)(NXI * p.Cin * p.Nw) * 4u);
 
     // ---- this thread's item: tile pt (0..31) and channel c8 (0..7) of the chunk; its 6x6 patch, top-left (gy0, gx0) ------
-    const int pt = tid & 31, c8 = tid >> 5;
+    const int pt = tid & 31, c8 = (tid & 255) >> 5;  // (NG = 2: both halves map their 256 threads onto the 256 items of a chunk)
     const int pty = pt / TC, ptx = pt % TC;
     const int gy0 = y0 + 4 * pty - 1, gx0 = x0 + 4 * ptx - 1;
     const bool left = gx0 < 0, right = gx0 + 5 >= p.W;
@@ -215,11 +226,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino4_kernel(ConvArgs p) {
     };
 
     const int nch = p.Cin / KC;
-    pload(0);
+#ifndef W4_EXP
+#define W4_EXP 0  // timing experiments (wrong results): 1 weight DMA only for chunk 0, 2 no patch transform, 4 no MFMA, 8 no patch loads
+#endif
+    if (NG == 1 || half == 0) pload(0);
+    else if (nch > 1) pload(1);  // NG = 2: half h transforms the chunks c = h mod 2 and fetches their patches
     lds_barrier();  // epilogue tables visible
     for (int ch = 0; ch < nch; ++ch) {
         lds_barrier();  // previous chunk's MFMAs have finished reading V / U
         __builtin_amdgcn_s_setprio(2);
+        const bool duty = NG == 1 || half == (ch & 1);  // (wave-uniform) this wave transforms chunk ch
+        if (NG == 1) {
         // The patch of this chunk was requested a whole MFMA phase ago.  Pin it as arrived HERE: hipcc counts only its own
         // loads, so a wait placed behind the LDS-DMA below would be vmcnt(0) and drain the weight slab before the transform.
 #pragma unroll
@@ -228,9 +245,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino4_kernel(ConvArgs p) {
         }
         if (PRO) asm volatile("" : "+v"(ps), "+v"(ph));
         // weight slab of (chunk ch, cout group n0 / 32): 36 pieces of 1 KiB, 9 per wave
-#ifndef W4_EXP
-#define W4_EXP 0  // timing experiments (wrong results): 1 weight DMA only for chunk 0, 2 no patch transform, 4 no MFMA, 8 no patch loads
-#endif
         if (!(W4_EXP & 1) || ch == 0)
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
@@ -247,6 +261,24 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino4_kernel(ConvArgs p) {
             wait_vmcnt<NLOAD>();  // this wave's pieces of U(ch) have landed; the patch of chunk ch+1 stays in flight
         else
             wait_vmcnt<0>();
+        } else if (duty) {
+            // transform half: the patch (requested two chunks ago) -> V; then request the patch of this half's next chunk, which
+            // stays in flight through the MFMA phases (this half issues no LDS-DMA: hipcc's own load accounting is exact here)
+            if (!(W4_EXP & 2) || ch == 0) pprocess();
+            __builtin_amdgcn_sched_barrier(0);
+            if (ch + 2 < nch && !(W4_EXP & 8)) pload(ch + 2);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            // DMA half: the two adjacent 32-cout slabs of (chunk ch, cout block n0 / 64) = 72 pieces of 1 KiB, 18 per wave.
+            // (Its own patch loads for chunk ch + 1, requested a chunk ago, are older than these pieces: vmcnt(0) covers both.)
+            if (!(W4_EXP & 1) || ch == 0)
+#pragma unroll
+            for (int i = 0; i < 18; ++i) {
+                const unsigned piece = (unsigned)((wave & 3) * 18 + i) * 1024u;
+                lds_dma_16B(uw, ulane, (unsigned)ch * slab_pitch + slab_n0 + piece, lu_addr + piece);
+            }
+            wait_vmcnt<0>();
+        }
         lds_barrier();  // V visible, every wave's U pieces landed
         __builtin_amdgcn_s_setprio(0);
         // 36 GEMM steps x 2 k-steps; two xi in flight so that no MFMA depends on its predecessor (40-cycle dependent latency)
@@ -461,22 +493,36 @@ __global__ __launch_bounds__(256) void wino4_weights_kernel(const float* __restr
         }
 }
 
-template <int TC, int FLAGS>
+template <int TC, int FLAGS, int NG>
 hipError_t launch_wino4_tc(const ConvArgs& p0, hipStream_t stream) {
     ConvArgs p = p0;
     constexpr int OR_ = 4 * (32 / TC), OC = 4 * TC;
     p.gx = (p.W / OC) * ((p.H + OR_ - 1) / OR_);
-    p.gy = p.N / 32;
+    p.gy = p.N / (32 * NG);
     static const int xcd = [] { const char* e = getenv("LASS_XCD_MAP"); return e ? atoi(e) : 2; }();
     p.xcd_map = (xcd && ((long)p.gx * p.B) % 8 == 0 && (p.gy > 1 || xcd == 2)) ? xcd : 0;
-    hipLaunchKernelGGL((wino4_kernel<TC, FLAGS>), dim3((unsigned)((long)p.gx * p.gy * p.B)), dim3(NTHREADS), 0, stream, p);
+    hipLaunchKernelGGL((wino4_kernel<TC, FLAGS, NG>), dim3((unsigned)((long)p.gx * p.gy * p.B)), dim3(NTHREADS * NG), 0, stream, p);
     return hipGetLastError();
 }
 
+// LASS_WINO4_NG=2 runs the launches with N % 64 == 0 at 64 couts per workgroup (NG = 2).  Measured A/B on one box, round 5
+// (gpurun_out/r5j): 983 vs 1 015 clips/s, conv3x3 class 15.3 vs 14.4 ms - SLOWER by 6 %: the transform count per MFMA halves
+// as designed, but the single 8-wave workgroup of a CU meets at two barriers per chunk with no second workgroup to run in its
+// waits, and U (72 KiB) + V (36 KiB) leave no room to double-buffer either operand.  Default stays NG = 1.
 template <int FLAGS>
 hipError_t launch_wino4(const ConvArgs& p, hipStream_t stream) {
-    if (p.W % 64 == 0 && p.H % 8 == 0) return launch_wino4_tc<16, FLAGS>(p, stream);  // 8 rows x 64 columns
-    if (p.H % 16 == 0) return launch_wino4_tc<8, FLAGS>(p, stream);                   // 16 rows x 32 columns
+    constexpr bool CAN2 = (FLAGS & (F_MASK | F_PRECONV | F_RESPRE)) == 0;
+    const char* ng_env = getenv("LASS_WINO4_NG");  // (read per launch: the parity test switches it inside one process)
+    const int ngmax = ng_env ? atoi(ng_env) : 1;
+    if constexpr (CAN2) {
+        if (ngmax >= 2 && p.N % 64 == 0) {
+            if (p.W % 64 == 0 && p.H % 8 == 0) return launch_wino4_tc<16, FLAGS, 2>(p, stream);
+            if (p.H % 16 == 0) return launch_wino4_tc<8, FLAGS, 2>(p, stream);
+            return hipErrorInvalidValue;
+        }
+    }
+    if (p.W % 64 == 0 && p.H % 8 == 0) return launch_wino4_tc<16, FLAGS, 1>(p, stream);  // 8 rows x 64 columns
+    if (p.H % 16 == 0) return launch_wino4_tc<8, FLAGS, 1>(p, stream);                   // 16 rows x 32 columns
     return hipErrorInvalidValue;
 }
 

@@ -621,7 +621,8 @@ def test_fusion_switches_agree(synthetic_sd, monkeypatch):
     for env in ({"LASS_FUSE_MASK": "0"}, {"LASS_FUSE_POOL": "0", "LASS_FUSE_PRECONV": "0"}, {"LASS_WINO": "0"},
                 {"LASS_WINO": "0", "LASS_FUSE_MASK": "0"}, {"LASS_WINO32": "0"}, {"LASS_WINO32": "0", "LASS_FUSE_MASK": "0"},
                 {"LASS_WINO32": "0", "LASS_FUSE_PRECONV": "0"}, {"LASS_WINO4": "0"}, {"LASS_WINO4": "0", "LASS_WINO32": "0"},
-                {"LASS_WINO4": "64"}, {"LASS_WINO4": "0", "LASS_FUSE_MASK": "0"}):
+                {"LASS_WINO4": "64"}, {"LASS_WINO4": "0", "LASS_FUSE_MASK": "0"},
+                {"LASS_WINO4_NG": "2"}):   # round 5: 64 couts per workgroup (8 waves; measured slower, kept as a switch)
         got = run(env)
         assert float((got - ref).pow(2).mean().sqrt()) < 2e-5 * scale, env
 
