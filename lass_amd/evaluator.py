@@ -106,8 +106,7 @@ class _Slot:
 
 class DCASEEvaluator:
     def __init__(self, sampling_rate=16000, eval_indexes="lass_synthetic_validation.csv", audio_dir="lass_validation",
-                 batch_size: int = 16, device_mixing: bool = True, io_workers: int = 2, resident: bool = True,
-                 fill_workers: int = 8) -> None:
+                 batch_size: int = 16, device_mixing: bool = True, io_workers: int = 2, resident: bool = True) -> None:
         r"""DCASE T9 LASS evaluator (dcase_evaluator.py:28-47)."""
         self.sampling_rate = sampling_rate
         with open(eval_indexes) as csv_file:
@@ -121,7 +120,6 @@ class DCASEEvaluator:
         self.last_rows = None  # (N,3) per-clip [sdr, sdri, sisdr] of the last call (all ranks)
         self._embed_cache: Dict[str, torch.Tensor] = {}
         self.resident = resident
-        self.fill_workers = max(1, fill_workers)
         self._slots = {}       # (B, L, device) -> [two _Slot]: kept across calls, so later calls replay graphs from their first batch
         self.last_path = None  # "resident" / "generic": which data path the last call took (tests, bench)
         self.resident_batches = self.generic_batches = 0
@@ -219,10 +217,10 @@ class DCASEEvaluator:
             return self._read_pair(items[k])
 
         pending_stats, rows_out = [], []
-        # two pools: the FIRST two batches are decoded by a burst of `fill_workers` threads (nothing else is running yet: the GPU
-        # idles until batch 0 is on it), everything after by `io_workers` threads that share the box with the launching thread
-        with torch.no_grad(), ThreadPoolExecutor(max_workers=self.io_workers) as pool, \
-                ThreadPoolExecutor(max_workers=max(self.io_workers, self.fill_workers)) as burst:
+        # (a burst of 8 / 16 decode threads for the first two batches - the GPU idles until batch 0 is on it - was measured SLOWER
+        # than the steady two: 0.946 / 0.940 vs 0.955 of the separator, same process; the extra threads contend with the launching
+        # thread and the HIP runtime's own)
+        with torch.no_grad(), ThreadPoolExecutor(max_workers=self.io_workers) as pool:
             futures = {}
             submitted = 0  # batches whose decode jobs are out
 
@@ -233,9 +231,8 @@ class DCASEEvaluator:
                     if slot.h2d_done is not None:
                         slot.h2d_done.synchronize()  # the copy of batch `submitted - 2` out of these pinned rows (long done)
                         slot.h2d_done = None
-                    ex = burst if submitted < 2 else pool
                     for k in range(submitted * B, min(n, (submitted + 1) * B)):
-                        futures[k] = ex.submit(decode, k)
+                        futures[k] = pool.submit(decode, k)
                     submitted += 1
 
             submit_ready(2)
