@@ -40,6 +40,22 @@ def test_bench_parent_builds_launch_command_without_touching_torch():
     assert "torch" not in imported and "numpy" not in imported
 
 
+def test_bench_workload_switch_defaults():
+    """`--workload multistft` (configs[4]'s per-rank job) changes the defaults of --batch / --length only; the launch command the
+    parent assembles carries the switch to every rank."""
+    sys.path.insert(0, ROOT)
+    import importlib
+    bench = importlib.import_module("bench")
+    a = bench.parse_args([])
+    assert (a.workload, a.batch, a.length, a.gpus, a.dtype) == ("resunet30", 16, 160000, 1, "f32")
+    m = bench.parse_args(["--workload", "multistft"])
+    assert (m.batch, m.length) == (1, 960000)
+    m2 = bench.parse_args(["--workload", "multistft", "--batch", "2", "--length", "320000"])
+    assert (m2.batch, m2.length) == (2, 320000)
+    cmd = bench.launch_command(["--gpus", "8", "--workload", "multistft"], 8, 12345)
+    assert cmd[-4:] == ["--gpus", "8", "--workload", "multistft"] and "--nproc-per-node=8" in cmd
+
+
 def test_bench_rank_refuses_mismatched_world():
     env = _env()
     env.update(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
